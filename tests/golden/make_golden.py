@@ -1,0 +1,315 @@
+"""Generate golden vectors by IMPORTING THE REAL REFERENCE (/root/reference) in the build container.
+
+Run:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+
+Fixtures are data only (inputs + the reference's outputs); no reference source is copied. The
+reference cannot travel to the GPU box, these files can. Inputs are generated from the counter-based
+generator in yolov5m_amd/utils/synth.py or from seeded numpy, and are stored in the fixture so tests
+never depend on RNG reproducibility.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import ref_import                      # noqa: E402
+from yolov5m_amd.utils.synth import synth_state_dict, synth_images, synth_labels, uniform  # noqa: E402
+
+R = ref_import.load()
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def ref_model(nc=80):
+    m = R.YOLOV5m(first_out=48, nc=nc, anchors=R.config.ANCHORS, ch=(192, 384, 768))
+    return m
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_giou():
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0, 10, (1000, 4)).astype(np.float32)
+    b = rng.uniform(0, 10, (1000, 4)).astype(np.float32)
+    # degenerate rows: zero-size, identical, disjoint, contained
+    a[0] = [1, 1, 0, 0]; b[0] = [1, 1, 0, 0]
+    a[1] = [5, 5, 2, 2]; b[1] = [5, 5, 2, 2]
+    a[2] = [1, 1, 1, 1]; b[2] = [8, 8, 1, 1]
+    a[3] = [5, 5, 6, 6]; b[3] = [5, 5, 1, 1]
+    a[4] = [0, 0, 0, 3]; b[4] = [0, 0, 3, 0]
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    iou = R.intersection_over_union(ta, tb, GIoU=False).numpy()
+    giou = R.intersection_over_union(ta, tb, GIoU=True).numpy()
+    save("g1_giou", a=a, b=b, iou=iou, giou=giou)
+
+
+# ------------------------------------------------------------------------------------------------
+def _bt_cases():
+    rng = np.random.default_rng(2)
+    cases = []
+    # (name, targets (nt,6), shapes)
+    s640 = [(80, 80), (40, 40), (20, 20)]
+    t = synth_labels(4, 8).numpy()
+    cases.append(("synth_b4", t, s640))
+    t = synth_labels(16, 8, seed="lab2").numpy()
+    cases.append(("synth_b16", t, s640))
+    # config-0 recipe style: randint/100 boxes incl. zero w/h
+    t = np.zeros((12, 6), np.float32)
+    t[:, 0] = np.repeat(np.arange(4), 3); t[:, 1] = np.repeat(np.arange(4), 3)
+    t[:, 2:] = rng.integers(0, 50, (12, 4)) / 100
+    cases.append(("cfg0_style", t.astype(np.float32), s640))
+    # exact-integer grid coordinates (both +/- neighbours fire), borders, ratio == 4.0 boundary
+    t = np.array([
+        [0, 1, 0.5, 0.5, 0.1, 0.1],          # gx = 40.0, 20.0, 10.0 exactly
+        [0, 2, 0.25, 0.75, 0.2, 0.05],
+        [1, 3, 1.0, 1.0, 0.05, 0.05],        # on the far border: gx = nx -> clamp
+        [1, 4, 0.0, 0.0, 0.05, 0.05],        # on the near border
+        [1, 5, 0.00625, 0.99, 0.03, 0.04],   # < 1 cell from border
+        [2, 6, 0.5, 0.5, 4.0 * 1.25 / 80, 1.625 / 80],   # w ratio == 4.0 exactly on scale 0 anchor 0
+        [2, 7, 0.5, 0.5, 1.25 / 80 / 4.0, 1.625 / 80],   # 1/r == 4.0
+        [2, 8, 0.3, 0.3, 0.0, 0.1],          # zero width -> inf ratio
+        [3, 9, 0.7123, 0.2877, 0.11, 0.23],
+        [3, 9, 0.7123, 0.2877, 0.11, 0.23],  # duplicate target -> duplicate cells
+        [3, 10, 0.7125, 0.2875, 0.12, 0.22],  # same cell, different box
+    ], np.float32)
+    cases.append(("edges", t, s640))
+    cases.append(("rect", synth_labels(2, 5, seed="lab3").numpy(), [(48, 80), (24, 40), (12, 20)]))
+    cases.append(("tiny", synth_labels(2, 6, seed="lab4").numpy(), [(8, 8), (4, 4), (2, 2)]))
+    cases.append(("empty", np.zeros((0, 6), np.float32), s640))
+    cases.append(("one", np.array([[0, 17, 0.51, 0.49, 0.3, 0.4]], np.float32), s640))
+    return cases
+
+
+def g2_build_targets(model):
+    lf = R.ComputeLoss(model)
+    out = {}
+    names = []
+    for name, t, shapes in _bt_cases():
+        p = [torch.zeros(4, 3, ny, nx, 85) for (ny, nx) in shapes]
+        tcls, tbox, indices, anch = lf.build_targets(p, torch.from_numpy(t))
+        names.append(name)
+        out[f"{name}/targets"] = t
+        out[f"{name}/shapes"] = np.array(shapes, np.int64)
+        for i in range(3):
+            b, a, gj, gi = indices[i]
+            out[f"{name}/{i}/b"] = b.numpy().astype(np.int64).reshape(-1)
+            out[f"{name}/{i}/a"] = a.numpy().astype(np.int64).reshape(-1)
+            out[f"{name}/{i}/gj"] = gj.numpy().astype(np.int64).reshape(-1)
+            out[f"{name}/{i}/gi"] = gi.numpy().astype(np.int64).reshape(-1)
+            out[f"{name}/{i}/tbox"] = tbox[i].numpy().astype(np.float32).reshape(-1, 4)
+            out[f"{name}/{i}/anch"] = anch[i].numpy().astype(np.float32).reshape(-1, 2)
+            out[f"{name}/{i}/tcls"] = tcls[i].numpy().astype(np.int64).reshape(-1)
+    out["names"] = np.array(names)
+    save("g2_build_targets", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def g3_compute_loss(model):
+    lf = R.ComputeLoss(model)
+    out = {}
+    names = []
+    cases = [
+        ("tiny_b2", 2, [(8, 8), (4, 4), (2, 2)], synth_labels(2, 6, seed="lab4").numpy()),
+        ("mid_b3", 3, [(16, 24), (8, 12), (4, 6)], synth_labels(3, 7, seed="lab5").numpy()),
+        ("empty_b2", 2, [(8, 8), (4, 4), (2, 2)], np.zeros((0, 6), np.float32)),
+        ("dups_b2", 2, [(8, 8), (4, 4), (2, 2)], np.array(
+            [[0, 3, 0.5, 0.5, 0.4, 0.5], [0, 3, 0.5, 0.5, 0.4, 0.5], [1, 5, 0.51, 0.52, 0.5, 0.6],
+             [1, 7, 0.52, 0.51, 0.7, 0.4], [1, 7, 0.25, 0.75, 0.3, 0.3]], np.float32)),
+        ("b4_640", 4, [(80, 80), (40, 40), (20, 20)], synth_labels(4, 8).numpy()),
+    ]
+    for name, B, shapes, t in cases:
+        p = [(uniform(f"g3/{name}/{i}", (B, 3, ny, nx, 85), -3.0, 3.0)).requires_grad_(True)
+             for i, (ny, nx) in enumerate(shapes)]
+        loss = lf(p, torch.from_numpy(t), None)
+        loss.backward()
+        names.append(name)
+        out[f"{name}/targets"] = t
+        out[f"{name}/shapes"] = np.array(shapes, np.int64)
+        out[f"{name}/B"] = np.array(B)
+        out[f"{name}/loss"] = loss.detach().numpy()
+        for i in range(3):
+            if name != "b4_640":
+                out[f"{name}/p{i}"] = p[i].detach().numpy()
+                out[f"{name}/g{i}"] = p[i].grad.numpy()
+            else:   # too big to store: inputs are regenerated from the counter generator; keep checksums
+                g = p[i].grad.numpy()
+                out[f"{name}/g{i}_sum"] = np.array(g.astype(np.float64).sum())
+                out[f"{name}/g{i}_abs"] = np.array(np.abs(g.astype(np.float64)).sum())
+                out[f"{name}/g{i}_obj_sample"] = g[..., 4].reshape(-1)[::97].copy()
+    out["names"] = np.array(names)
+    save("g3_compute_loss", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def g4_yolo_loss(model):
+    """Fresh YOLO_LOSS object, pinned call sequence (anchors decay in place per box)."""
+    lf = R.YOLO_LOSS(model, rect_training=False)
+    out = {}
+    shapes = [(8, 8), (4, 4), (2, 2)]
+    B = 2
+    rng = np.random.default_rng(4)
+    calls = []
+    for call in range(2):
+        p = [uniform(f"g4/{call}/{i}", (B, 3, ny, nx, 85), -3.0, 3.0).requires_grad_(True)
+             for i, (ny, nx) in enumerate(shapes)]
+        boxes = []
+        for b in range(B):
+            n = 3
+            arr = np.zeros((n, 5), np.float64)
+            arr[:, 0] = rng.integers(0, 80, n)
+            arr[:, 1:3] = rng.uniform(0.1, 0.9, (n, 2))
+            arr[:, 3:5] = rng.uniform(0.05, 0.6, (n, 2))
+            boxes.append(arr)
+        # dense targets as the reference builds them (before compute_loss mutates them)
+        anchors_before = lf.anchors.clone()
+        loss = lf(p, tuple(boxes), pred_size=(64, 64))
+        loss.backward()
+        out[f"{call}/anchors_before"] = anchors_before.numpy()
+        out[f"{call}/anchors_after"] = lf.anchors.clone().numpy()
+        out[f"{call}/loss"] = loss.detach().numpy()
+        for b in range(B):
+            out[f"{call}/boxes{b}"] = boxes[b]
+        for i in range(3):
+            out[f"{call}/p{i}"] = p[i].detach().numpy()
+            out[f"{call}/g{i}"] = p[i].grad.numpy()
+        calls.append(call)
+    # dense targets for a fresh object, first image only (exact)
+    lf2 = R.YOLO_LOSS(model, rect_training=False)
+    p = [torch.zeros(1, 3, ny, nx, 85) for (ny, nx) in shapes]
+    tg = lf2.build_targets(p, out["0/boxes0"], (64, 64))
+    for i in range(3):
+        out[f"bt/t{i}"] = tg[i].numpy()
+    out["shapes"] = np.array(shapes, np.int64)
+    out["B"] = np.array(B)
+    save("g4_yolo_loss", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def g5_model(model):
+    sd = synth_state_dict()
+    out = {}
+    for tag, (B, H, W) in {"s64": (1, 64, 64), "s96x128": (2, 96, 128), "s320": (2, 320, 320)}.items():
+        x = synth_images(B, H, W)
+        for mode in ("eval", "train"):
+            model.load_state_dict(sd, strict=True)
+            model.train(mode == "train")
+            with torch.no_grad():
+                o = model(x.clone())
+            for i in range(3):
+                flat = o[i].reshape(-1).numpy()
+                step = max(1, flat.size // 4096)
+                out[f"{tag}/{mode}/o{i}_sample"] = flat[::step][:4096].copy()
+                out[f"{tag}/{mode}/o{i}_step"] = np.array(step)
+                out[f"{tag}/{mode}/o{i}_sum"] = np.array(flat.astype(np.float64).sum())
+                out[f"{tag}/{mode}/o{i}_abs"] = np.array(np.abs(flat.astype(np.float64)).sum())
+                if tag == "s64":
+                    out[f"{tag}/{mode}/o{i}"] = o[i].numpy()
+            if mode == "train":
+                nsd = model.state_dict()
+                for k in ("backbone.0.cbl.1.running_mean", "backbone.0.cbl.1.running_var",
+                          "neck.7.c_out.cbl.1.running_mean", "neck.7.c_out.cbl.1.running_var",
+                          "backbone.9.c_out.cbl.1.running_var"):
+                    out[f"{tag}/train/{k}"] = nsd[k].numpy().copy()
+    # one full training step's gradients at a small size: ComputeLoss + backward
+    B, H, W = 2, 96, 128
+    model.load_state_dict(sd, strict=True)
+    model.train(True)
+    model.zero_grad()
+    x = synth_images(B, H, W)
+    t = synth_labels(B, 5, seed="lab3")
+    lf = R.ComputeLoss(model)
+    o = model(x.clone())
+    loss = lf(o, t, None)
+    loss.backward()
+    out["step/loss"] = loss.detach().numpy()
+    out["step/targets"] = t.numpy()
+    named = dict(model.named_parameters())
+    for k in ("backbone.0.cbl.0.weight", "backbone.0.cbl.1.weight", "backbone.0.cbl.1.bias",
+              "backbone.2.seq.1.c2.cbl.0.weight", "backbone.4.c_out.cbl.0.weight",
+              "backbone.9.c1.cbl.0.weight", "backbone.9.c_out.cbl.1.weight", "neck.0.cbl.0.weight",
+              "neck.3.seq.1.1.cbl.0.weight", "neck.4.cbl.0.weight", "neck.7.c_out.cbl.0.weight",
+              "head.out_convs.0.weight", "head.out_convs.1.bias", "head.out_convs.2.weight"):
+        out[f"step/grad/{k}"] = named[k].grad.numpy().copy()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()))
+    out["step/grad_norm"] = np.array(float(gn))
+    save("g5_model", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def g6_decode_nms(model):
+    out = {}
+    anchors = model.head.anchors
+    strides = model.head.stride
+    # decode on small grids
+    shapes = [(8, 12), (4, 6), (2, 3)]
+    B = 2
+    p = [uniform(f"g6/dec/{i}", (B, 3, ny, nx, 85), -6.0, 6.0) for i, (ny, nx) in enumerate(shapes)]
+    p[0][0, 0, 0, 0, 5:] = 30.0      # fp32-saturated sigmoid tie -> lowest class index wins
+    p[0][0, 0, 0, 1, 5:] = -30.0
+    dec = R.cells_to_bboxes([t.clone() for t in p], anchors, strides, is_pred=True, to_list=False)
+    for i in range(3):
+        out[f"dec/p{i}"] = p[i].numpy()
+    out["dec/out"] = dec.numpy()
+    # is_pred=False branch (dense targets -> boxes)
+    tg = [uniform(f"g6/dect/{i}", (B, 3, ny, nx, 6), 0.0, 1.0) for i, (ny, nx) in enumerate(shapes)]
+    dect = R.cells_to_bboxes([t.clone() for t in tg], anchors, strides, is_pred=False, to_list=False)
+    for i in range(3):
+        out[f"dect/t{i}"] = tg[i].numpy()
+    out["dect/out"] = dect.numpy()
+    # NMS cases: (B,N,6) inputs -> reference wrapper (around the restated torchvision nms)
+    rng = np.random.default_rng(6)
+    names = []
+    for N in (0, 1, 64, 65, 1000, 5000):
+        for (thr, iou) in ((0.01, 0.6), (0.25, 0.45)):
+            Bn = 2
+            bx = np.zeros((Bn, N, 6), np.float32)
+            bx[..., 0] = rng.integers(0, 80, (Bn, N))
+            bx[..., 1] = rng.uniform(0, 1, (Bn, N)) ** 2
+            bx[..., 2:4] = rng.uniform(0, 640, (Bn, N, 2))
+            bx[..., 4:6] = rng.uniform(4, 200, (Bn, N, 2))
+            name = f"n{N}_t{thr}_i{iou}"
+            names.append(name)
+            res = R.non_max_suppression(torch.from_numpy(bx.copy()), iou_threshold=iou, threshold=thr,
+                                        max_detections=300, tolist=True)
+            out[f"nms/{name}/in"] = bx
+            out[f"nms/{name}/thr"] = np.array([thr, iou])
+            for b in range(Bn):
+                out[f"nms/{name}/out{b}"] = np.array(res[b], np.float32).reshape(-1, 6)
+    # clustered boxes (heavy overlap, few survivors) + many survivors > 300
+    N = 3000
+    bx = np.zeros((1, N, 6), np.float32)
+    centers = rng.uniform(100, 500, (12, 2))
+    cid = rng.integers(0, 12, N)
+    bx[0, :, 0] = rng.integers(0, 3, N)
+    bx[0, :, 1] = rng.uniform(0.02, 1, N)
+    bx[0, :, 2:4] = centers[cid] + rng.normal(0, 4, (N, 2))
+    bx[0, :, 4:6] = rng.uniform(60, 80, (N, 2))
+    res = R.non_max_suppression(torch.from_numpy(bx.copy()), iou_threshold=0.45, threshold=0.25,
+                                max_detections=300, tolist=True)
+    names.append("clustered")
+    out["nms/clustered/in"] = bx
+    out["nms/clustered/thr"] = np.array([0.25, 0.45])
+    out["nms/clustered/out0"] = np.array(res[0], np.float32).reshape(-1, 6)
+    out["nms/names"] = np.array(names)
+    save("g6_decode_nms", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    torch.manual_seed(0)
+    model = ref_model()
+    if "g1" in which: g1_giou()
+    if "g2" in which: g2_build_targets(model)
+    if "g3" in which: g3_compute_loss(model)
+    if "g4" in which: g4_yolo_loss(model)
+    if "g6" in which: g6_decode_nms(model)
+    if "g5" in which: g5_model(model)
