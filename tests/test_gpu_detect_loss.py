@@ -1,0 +1,247 @@
+"""GPU parity: HIP decode / NMS / IoU / build_targets / ComputeLoss (through the C ABI) against the
+CPU oracle and the golden fixtures generated from the real reference."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_ref
+from yolov5m_amd.utils.synth import synth_state_dict, synth_labels, uniform
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def anchors():
+    return synth_state_dict()["head.anchors"]
+
+
+class _StubModel:
+    """what ComputeLoss reads from a model (reference ultralytics_loss.py:22,31-41)."""
+
+    def __init__(self, anchors, nc=80):
+        self.head = types.SimpleNamespace(nc=nc, nl=3, naxs=3, anchors=anchors.to(DEV), stride=[8, 16, 32])
+        self._p = torch.nn.Parameter(torch.zeros(1, device=DEV))
+
+    def parameters(self):
+        return iter([self._p])
+
+
+# ---------------------------------------------------------------------------------------------- decode
+def test_decode_golden(golden, anchors):
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    g = golden("g6_decode_nms")
+    p = [torch.from_numpy(g[f"dec/p{i}"]).to(DEV) for i in range(3)]
+    out = cells_to_bboxes(p, anchors.to(DEV), [8, 16, 32], is_pred=True, to_list=False).cpu().numpy()
+    ref = g["dec/out"]
+    assert np.array_equal(out[..., 0], ref[..., 0])            # class index exact (incl. saturated ties)
+    np.testing.assert_allclose(out[..., 1:], ref[..., 1:], rtol=1e-4, atol=1e-6)   # SURVEY B.4 tolerance
+    t = [torch.from_numpy(g[f"dect/t{i}"]).to(DEV) for i in range(3)]
+    out = cells_to_bboxes(t, anchors.to(DEV), [8, 16, 32], is_pred=False, to_list=False).cpu().numpy()
+    assert np.array_equal(out, g["dect/out"])
+
+
+def test_decode_vs_oracle_640(anchors):
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    shapes = [(80, 80), (40, 40), (20, 20)]
+    p = [uniform(f"dec640/{i}", (3, 3, ny, nx, 85), -8.0, 8.0) for i, (ny, nx) in enumerate(shapes)]
+    ref = loss_ref.cells_to_bboxes(p, anchors, [8, 16, 32], is_pred=True).numpy()
+    out = cells_to_bboxes([t.to(DEV) for t in p], anchors.to(DEV), [8, 16, 32], is_pred=True, to_list=False)
+    out = out.cpu().numpy()
+    assert out.shape == (3, 25200, 6)
+    assert (out[..., 0] != ref[..., 0]).mean() < 1e-4        # argmax may flip only on near-ties
+    np.testing.assert_allclose(out[..., 1:], ref[..., 1:], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- NMS
+def _check_nms(bx, thr, iou, max_det=300):
+    from yolov5m_amd.utils.bboxes_utils import nms_batched, non_max_suppression
+    ref = loss_ref.non_max_suppression(bx, iou, thr, max_det)
+    rows, idx, cnt = nms_batched(torch.from_numpy(bx).to(DEV), iou, thr, max_det)
+    rows, idx, cnt = rows.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(bx.shape[0]):
+        rr, ri = ref[b]
+        assert cnt[b] == len(ri), (b, cnt[b], len(ri))
+        assert np.array_equal(idx[b, :cnt[b]], ri), f"image {b}: kept index set differs"
+        assert np.array_equal(rows[b, :cnt[b]].view(np.uint32), rr.view(np.uint32)), f"image {b}: rows differ"
+    return ref
+
+
+def test_nms_golden_bit_exact(golden):
+    g = golden("g6_decode_nms")
+    for name in g["nms/names"]:
+        bx = g[f"nms/{name}/in"]
+        thr, iou = g[f"nms/{name}/thr"]
+        if bx.shape[1] == 0:
+            continue
+        ref = _check_nms(bx, float(thr), float(iou))
+        for b in range(bx.shape[0]):     # and the reference's own output rows
+            assert np.array_equal(ref[b][0].view(np.uint32), g[f"nms/{name}/out{b}"].view(np.uint32))
+
+
+def test_nms_api_shapes(golden):
+    from yolov5m_amd.utils.bboxes_utils import non_max_suppression
+    g = golden("g6_decode_nms")
+    bx = g["nms/n1000_t0.25_i0.45/in"]
+    lst = non_max_suppression(torch.from_numpy(bx).to(DEV), 0.45, 0.25, 300, tolist=True)
+    assert isinstance(lst, list) and len(lst) == 2 and all(len(r) == 6 for r in lst[0])
+    assert np.array_equal(np.array(lst[0], np.float32), g["nms/n1000_t0.25_i0.45/out0"])
+    cat = non_max_suppression(torch.from_numpy(bx).to(DEV), 0.45, 0.25, 300, tolist=False)
+    assert cat.shape == (len(lst[0]) + len(lst[1]), 6)
+
+
+@pytest.mark.parametrize("N,thr,iou", [(25200, 0.01, 0.6), (25200, 0.25, 0.45), (100800, 0.01, 0.6)])
+def test_nms_large_random(N, thr, iou):
+    """> NMS_CAP candidates: exercises the radix-select rounds."""
+    rng = np.random.default_rng(N)
+    B = 2
+    bx = np.zeros((B, N, 6), np.float32)
+    bx[..., 0] = rng.integers(0, 80, (B, N))
+    bx[..., 1] = rng.uniform(0, 1, (B, N))
+    bx[..., 2:4] = rng.uniform(0, 1280, (B, N, 2))
+    bx[..., 4:6] = rng.uniform(8, 120, (B, N, 2))
+    _check_nms(bx, thr, iou)
+
+
+def test_nms_heavy_overlap_many_rounds():
+    """few survivors among many candidates: every round of the select/sort/greedy loop runs."""
+    rng = np.random.default_rng(5)
+    N = 20000
+    bx = np.zeros((1, N, 6), np.float32)
+    centers = rng.uniform(100, 500, (8, 2))
+    cid = rng.integers(0, 8, N)
+    bx[0, :, 0] = 0
+    bx[0, :, 1] = rng.uniform(0.3, 1, N)
+    bx[0, :, 2:4] = centers[cid] + rng.normal(0, 2, (N, 2))
+    bx[0, :, 4:6] = rng.uniform(70, 80, (N, 2))
+    _check_nms(bx, 0.25, 0.45)
+
+
+def test_nms_edge_cases():
+    rng = np.random.default_rng(8)
+    # nothing passes / one passes / all identical boxes with tied scores (stable: lowest index first)
+    bx = np.zeros((3, 50, 6), np.float32)
+    bx[..., 4:6] = 10
+    bx[1, 7, 1] = 0.9
+    bx[2, :, 1] = 0.5
+    bx[2, :, 2:4] = 100
+    _check_nms(bx, 0.25, 0.45)
+    # tied scores on distinct boxes + max_det truncation
+    bx = np.zeros((1, 700, 6), np.float32)
+    bx[0, :, 1] = np.repeat(rng.uniform(0.3, 1, 70), 10)
+    bx[0, :, 2:4] = rng.uniform(0, 5000, (700, 2))
+    bx[0, :, 4:6] = 5
+    _check_nms(bx, 0.25, 0.45, max_det=300)
+    _check_nms(bx, 0.25, 0.45, max_det=17)
+
+
+# ---------------------------------------------------------------------------------------------- IoU
+def test_iou_golden(golden):
+    from yolov5m_amd.utils.bboxes_utils import intersection_over_union
+    g = golden("g1_giou")
+    a, b = torch.from_numpy(g["a"]).to(DEV), torch.from_numpy(g["b"]).to(DEV)
+    for flag, key in ((False, "iou"), (True, "giou")):
+        out = intersection_over_union(a, b, GIoU=flag).cpu().numpy()
+        assert out.shape == g[key].shape
+        np.testing.assert_allclose(out, g[key], rtol=1e-5, atol=1e-6)
+
+
+def test_iou_backward_vs_autograd():
+    from yolov5m_amd.utils.bboxes_utils import intersection_over_union
+    rng = np.random.default_rng(3)
+    a = torch.from_numpy(rng.uniform(0.5, 6, (500, 4)).astype(np.float32))
+    b = torch.from_numpy(rng.uniform(0.5, 6, (500, 4)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (500, 1)).astype(np.float32))
+    ac, bc = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (loss_ref.giou(ac, bc, GIoU=True) * w).sum().backward()
+    ag, bg = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    (intersection_over_union(ag, bg, GIoU=True) * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(ag.grad.cpu().numpy(), ac.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- targets
+def test_build_targets_golden_bit_exact(golden, anchors):
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    g = golden("g2_build_targets")
+    lf = ComputeLoss(_StubModel(anchors))
+    for name in g["names"]:
+        shapes = [tuple(s) for s in g[f"{name}/shapes"]]
+        p = [torch.zeros(4, 3, ny, nx, 85, device=DEV) for (ny, nx) in shapes]
+        tcls, tbox, indices, anch = lf.build_targets(p, torch.from_numpy(g[f"{name}/targets"]))
+        for i in range(3):
+            b, a, gj, gi = [t.cpu().numpy() for t in indices[i]]
+            assert np.array_equal(b, g[f"{name}/{i}/b"]), (name, i)
+            assert np.array_equal(a, g[f"{name}/{i}/a"]), (name, i)
+            assert np.array_equal(gj, g[f"{name}/{i}/gj"]), (name, i)
+            assert np.array_equal(gi, g[f"{name}/{i}/gi"]), (name, i)
+            assert np.array_equal(tcls[i].cpu().numpy(), g[f"{name}/{i}/tcls"]), (name, i)
+            assert np.array_equal(tbox[i].cpu().numpy().view(np.uint32), g[f"{name}/{i}/tbox"].view(np.uint32)), (name, i)
+            assert np.array_equal(anch[i].cpu().numpy().view(np.uint32), g[f"{name}/{i}/anch"].view(np.uint32)), (name, i)
+
+
+def test_build_targets_large_vs_oracle(anchors):
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    lf = ComputeLoss(_StubModel(anchors))
+    t = synth_labels(64, 8, seed="bt_large")          # nt = 512 (configs[2])
+    shapes = [(80, 80), (40, 40), (20, 20)]
+    p = [torch.zeros(64, 3, ny, nx, 85, device=DEV) for (ny, nx) in shapes]
+    tcls, tbox, indices, anch = lf.build_targets(p, t)
+    ref = loss_ref.build_targets_ultra(shapes, t.numpy(), anchors.numpy())
+    for i in range(3):
+        for k, v in zip(("b", "a", "gj", "gi"), indices[i]):
+            assert np.array_equal(v.cpu().numpy(), ref[i][k])
+        assert np.array_equal(tbox[i].cpu().numpy().view(np.uint32), ref[i]["tbox"].view(np.uint32))
+        assert np.array_equal(tcls[i].cpu().numpy(), ref[i]["tcls"])
+
+
+# ---------------------------------------------------------------------------------------------- loss
+def test_compute_loss_golden(golden, anchors):
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    g = golden("g3_compute_loss")
+    lf = ComputeLoss(_StubModel(anchors))
+    for name in g["names"]:
+        shapes = [tuple(s) for s in g[f"{name}/shapes"]]
+        B = int(g[f"{name}/B"])
+        if name == "b4_640":
+            p = [uniform(f"g3/{name}/{i}", (B, 3, ny, nx, 85), -3.0, 3.0) for i, (ny, nx) in enumerate(shapes)]
+        else:
+            p = [torch.from_numpy(g[f"{name}/p{i}"]) for i in range(3)]
+        p = [t.to(DEV).requires_grad_(True) for t in p]
+        loss = lf(p, torch.from_numpy(g[f"{name}/targets"]), None)
+        assert loss.shape == (1,)
+        loss.backward()
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g[f"{name}/loss"], rtol=1e-4)   # north_star tol
+        for i in range(3):
+            got = p[i].grad.cpu().numpy()
+            if name == "b4_640":
+                np.testing.assert_allclose(got.astype(np.float64).sum(), g[f"{name}/g{i}_sum"], rtol=1e-3)
+                np.testing.assert_allclose(np.abs(got.astype(np.float64)).sum(), g[f"{name}/g{i}_abs"], rtol=1e-4)
+                np.testing.assert_allclose(got[..., 4].reshape(-1)[::97], g[f"{name}/g{i}_obj_sample"], rtol=1e-4, atol=1e-9)
+            else:
+                ref = g[f"{name}/g{i}"]
+                assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, (name, i)
+
+
+def test_compute_loss_b64_vs_oracle(anchors):
+    """configs[2] label recipe (nt=512) at reduced grid so the CPU oracle finishes in seconds."""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    lf = ComputeLoss(_StubModel(anchors))
+    B = 64
+    shapes = [(20, 20), (10, 10), (5, 5)]
+    t = synth_labels(B, 8, seed="loss_b64")
+    p = [uniform(f"lb64/{i}", (B, 3, ny, nx, 85), -4.0, 4.0) for i, (ny, nx) in enumerate(shapes)]
+    pc = [x.clone().requires_grad_(True) for x in p]
+    lref, _ = loss_ref.compute_loss_ultra(pc, t, anchors)
+    lref.backward()
+    pg = [x.to(DEV).requires_grad_(True) for x in p]
+    l = lf(pg, t, None)
+    l.backward()
+    np.testing.assert_allclose(l.detach().cpu().numpy(), lref.detach().numpy(), rtol=1e-4)
+    for i in range(3):
+        ref = pc[i].grad.numpy()
+        got = pg[i].grad.cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9

@@ -1,0 +1,52 @@
+// Internal helpers shared by the HIP translation units of liby5m.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/y5m.h"
+
+extern "C" void y5m_set_error(const char* fmt, ...);
+
+#define Y5M_CHECK_LAUNCH(name)                                                       \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            y5m_set_error("%s: %s", name, hipGetErrorString(e__));                   \
+            return Y5M_ELAUNCH;                                                      \
+        }                                                                            \
+    } while (0)
+
+#define Y5M_REQUIRE(cond, msg)                                                       \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            y5m_set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond);         \
+            return Y5M_EINVAL;                                                       \
+        }                                                                            \
+    } while (0)
+
+static inline hipStream_t y5m_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t y5m_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- bf16 <-> f32 (round to nearest even), raw 16-bit storage -------------------------------
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

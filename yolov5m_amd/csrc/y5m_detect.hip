@@ -1,0 +1,501 @@
+// Detect path for gfx950: box decode, per-image NMS (one workgroup per image, LDS-resident
+// top-K selection + bitonic sort + wave-ballot greedy scan) and the IoU/GIoU entry points.
+//
+// Compiled with -ffp-contract=off: the NMS arithmetic must reproduce the CPU reference bit for bit
+// (SURVEY B.5/B.7): IEEE fp32 division, no FMA fusion, double compare against the IoU threshold.
+#include "y5m_box.h"
+
+// =================================================================================================
+// decode  (reference utils/plot_utils.py:10-54)
+// =================================================================================================
+#define DEC_THREADS 128
+#define DEC_WAVES (DEC_THREADS / 64)
+
+// One wave decodes 64 consecutive cells. The 64*(5+nc) logits of those cells are one contiguous
+// run in HBM: they are read with coalesced 16-byte loads into an LDS tile with an odd row stride,
+// then lane i walks the channels of cell i conflict-free.
+__global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel(
+    const float* __restrict__ logits, int64_t cells, int naxs, int ny, int nx, int nch,
+    float aw0, float ah0, float aw1, float ah1, float aw2, float ah2, float stride,
+    float* __restrict__ out, int64_t N_total, int64_t row_offset) {
+    extern __shared__ __attribute__((aligned(16))) float dec_lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lstride = nch | 1;
+    float* tile = dec_lds + (size_t)wid * 64 * lstride;
+    const int64_t c0 = ((int64_t)blockIdx.x * DEC_WAVES + wid) * 64;
+    if (c0 >= cells) return;
+    const int ncell = (int)((cells - c0) < 64 ? (cells - c0) : 64);
+    const int nelem = ncell * nch;
+    const float* src = logits + c0 * nch;
+    // coalesced fill: element e -> (cell = e / nch, ch = e % nch), tracked incrementally
+    if (((uintptr_t)src & 15) == 0) {
+        const int nvec = nelem >> 2;
+        for (int v = lane; v < nvec; v += 64) {
+            const float4 q = *reinterpret_cast<const float4*>(src + 4 * v);
+            int e = 4 * v;
+            int cell = e / nch, ch = e - cell * nch;
+            const float vals[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tile[cell * lstride + ch] = vals[k];
+                if (++ch == nch) { ch = 0; ++cell; }
+            }
+        }
+        for (int e = (nvec << 2) + lane; e < nelem; e += 64) {
+            int cell = e / nch, ch = e - cell * nch;
+            tile[cell * lstride + ch] = src[e];
+        }
+    } else {
+        for (int e = lane; e < nelem; e += 64) {
+            int cell = e / nch, ch = e - cell * nch;
+            tile[cell * lstride + ch] = src[e];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane >= ncell) return;
+    const float* row = tile + lane * lstride;
+    const int64_t cell = c0 + lane;
+    const int gx = (int)(cell % nx);
+    int64_t t = cell / nx;
+    const int gy = (int)(t % ny);
+    t /= ny;
+    const int a = (int)(t % naxs);
+    const int64_t b = t / naxs;
+    const float sx = sigmoidf_(row[0]), sy = sigmoidf_(row[1]);
+    const float sw = sigmoidf_(row[2]), sh = sigmoidf_(row[3]);
+    const float obj = sigmoidf_(row[4]);
+    const float aw = a == 0 ? aw0 : (a == 1 ? aw1 : aw2);
+    const float ah = a == 0 ? ah0 : (a == 1 ? ah1 : ah2);
+    // :25  xy = (2*s + grid - 0.5) * stride ;  :26  wh = ((2*s)**2) * (anchors*stride)
+    const float x = (2.0f * sx + (float)gx - 0.5f) * stride;
+    const float y = (2.0f * sy + (float)gy - 0.5f) * stride;
+    const float tw = 2.0f * sw, th = 2.0f * sh;
+    const float w = (tw * tw) * (aw * stride);
+    const float h = (th * th) * (ah * stride);
+    // :27 argmax over SIGMOID values (first max wins). sigmoid is monotone, so a class whose logit
+    // does not exceed the best logit so far cannot have a strictly larger sigmoid: skip its exp.
+    int best = 0;
+    float best_logit = row[5], best_sig = sigmoidf_(row[5]);
+    for (int c = 1; c < nch - 5; ++c) {
+        const float l = row[5 + c];
+        if (l > best_logit) {
+            const float s = sigmoidf_(l);
+            if (s > best_sig) { best_sig = s; best = c; best_logit = l; }
+        }
+    }
+    float* o = out + (b * N_total + row_offset + ((int64_t)a * ny + gy) * nx + gx) * 6;
+    reinterpret_cast<float2*>(o)[0] = make_float2((float)best, obj);
+    reinterpret_cast<float2*>(o)[1] = make_float2(x, y);
+    reinterpret_cast<float2*>(o)[2] = make_float2(w, h);
+}
+
+extern "C" int y5m_decode_scale(const float* logits, int B, int naxs, int ny, int nx, int nc,
+                                const float* anchors_scale_host, float stride, float* out,
+                                int64_t N_total, int64_t row_offset, void* stream) {
+    Y5M_REQUIRE(naxs == 3, "decode supports 3 anchors per scale");
+    Y5M_REQUIRE(B >= 0 && ny > 0 && nx > 0 && nc >= 1, "bad dims");
+    const int64_t cells = (int64_t)B * naxs * ny * nx;
+    if (cells == 0) return Y5M_OK;
+    const int nch = 5 + nc;
+    const size_t lds = (size_t)DEC_WAVES * 64 * (nch | 1) * sizeof(float);
+    Y5M_REQUIRE(lds <= 160 * 1024, "nc too large for the LDS tile");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)decode_pred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int64_t blocks = (cells + DEC_THREADS - 1) / DEC_THREADS;
+    const float* a = anchors_scale_host;
+    hipLaunchKernelGGL(decode_pred_kernel, dim3((unsigned)blocks), dim3(DEC_THREADS), lds, y5m_stream(stream),
+                       logits, cells, naxs, ny, nx, nch, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
+                       N_total, row_offset);
+    Y5M_CHECK_LAUNCH("decode_pred_kernel");
+    return Y5M_OK;
+}
+
+__global__ void decode_tgt_kernel(const float* __restrict__ tg, int64_t cells, int naxs, int ny, int nx,
+                                  float stride, float* __restrict__ out, int64_t N_total, int64_t row_offset) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells) return;
+    const float* r = tg + cell * 6;
+    const int gx = (int)(cell % nx);
+    int64_t t = cell / nx;
+    const int gy = (int)(t % ny);
+    t /= ny;
+    const int a = (int)(t % naxs);
+    const int64_t b = t / naxs;
+    float* o = out + (b * N_total + row_offset + ((int64_t)a * ny + gy) * nx + gx) * 6;
+    o[0] = r[5];
+    o[1] = r[4];
+    o[2] = (r[0] + (float)gx) * stride;   // plot_utils.py:32
+    o[3] = (r[1] + (float)gy) * stride;
+    o[4] = r[2] * stride;                 // :33
+    o[5] = r[3] * stride;
+}
+
+extern "C" int y5m_decode_targets_scale(const float* tgt, int B, int naxs, int ny, int nx, float stride,
+                                        float* out, int64_t N_total, int64_t row_offset, void* stream) {
+    const int64_t cells = (int64_t)B * naxs * ny * nx;
+    if (cells == 0) return Y5M_OK;
+    hipLaunchKernelGGL(decode_tgt_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, y5m_stream(stream),
+                       tgt, cells, naxs, ny, nx, stride, out, N_total, row_offset);
+    Y5M_CHECK_LAUNCH("decode_tgt_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// NMS  (reference utils/bboxes_utils.py:175-209 + torchvision 0.12 nms_kernel.cpp semantics)
+// =================================================================================================
+#define NMS_T 1024          // threads per image-workgroup (16 waves)
+#define NMS_CAP 4096        // keys sorted per round
+#define NMS_MAXK 1024       // upper bound for max_det
+#define NMS_HBITS 11
+#define NMS_HBINS (1 << NMS_HBITS)
+
+struct NmsLds {
+    unsigned long long keys[NMS_CAP];
+    float kbox[NMS_MAXK * 4];
+    float karea[NMS_MAXK];
+    float sbox[NMS_T * 4];
+    float sarea[NMS_T];
+    int sidx[NMS_T];
+    unsigned hist[NMS_HBINS];
+    int wave_tot[NMS_T / 64];
+    int red[NMS_T / 64];
+    int s_m;                      // gathered count
+    int s_nk;                     // kept so far
+    int s_ns;                     // survivors of the current group
+    unsigned s_digit;
+    unsigned s_need;
+    int s_done;
+};
+
+struct NmsBox { float x1, y1, x2, y2, area; };
+
+// reference utils/bboxes_utils.py:190-195 for one candidate row (exact op order)
+__device__ __forceinline__ void nms_load(const float* __restrict__ row, float& cls, float& score,
+                                         float& x1, float& y1, float& x2, float& y2, NmsBox& ob) {
+    cls = row[0]; score = row[1];
+    const float x = row[2], y = row[3], w = row[4], h = row[5];
+    x1 = x - (w / 2.0f);          // :190
+    y1 = y - (h / 2.0f);          // :191
+    y2 = h + y1;                  // :192
+    x2 = w + x1;                  // :193
+    ob.x1 = x1 + cls; ob.y1 = y1 + cls; ob.x2 = x2 + cls; ob.y2 = y2 + cls;   // :195
+    ob.area = (ob.x2 - ob.x1) * (ob.y2 - ob.y1);
+}
+
+// torchvision nms_kernel.cpp inner test; i = already kept (higher score), j = candidate
+__device__ __forceinline__ bool nms_suppresses(float ix1, float iy1, float ix2, float iy2, float iarea,
+                                               const NmsBox& j, double thr) {
+    const float xx1 = ix1 > j.x1 ? ix1 : j.x1;
+    const float yy1 = iy1 > j.y1 ? iy1 : j.y1;
+    const float xx2 = ix2 < j.x2 ? ix2 : j.x2;
+    const float yy2 = iy2 < j.y2 ? iy2 : j.y2;
+    float w = xx2 - xx1; w = w > 0.0f ? w : 0.0f;
+    float h = yy2 - yy1; h = h > 0.0f ? h : 0.0f;
+    const float inter = w * h;
+    const float ovr = inter / (iarea + j.area - inter);
+    return (double)ovr > thr;
+}
+
+// order-preserving transform: larger score -> smaller key (ascending sort = best first)
+__device__ __forceinline__ unsigned desc_key(float s) {
+    const unsigned u = __float_as_uint(s);
+    const unsigned asc = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    return ~asc;
+}
+
+__device__ __forceinline__ int block_sum(int v, int* red) {
+    v = wave_sum_i(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NMS_T / 64; ++i) t += red[i];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(NMS_T) void nms_kernel(
+    const float* __restrict__ boxes, int64_t N, float conf_thr, double iou_thr, int max_det, int ibits,
+    float* __restrict__ out_rows, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_count,
+    unsigned* __restrict__ ws_keys) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_raw[];
+    NmsLds& L = *reinterpret_cast<NmsLds*>(nms_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t img = blockIdx.x;
+    const float* bx = boxes + img * N * 6;
+    unsigned* skey = ws_keys + img * N;
+    float* orow = out_rows + img * (int64_t)max_det * 6;
+    int32_t* oidx = out_idx + img * (int64_t)max_det;
+    const int kbits = 32 + ibits;
+    const unsigned long long imask = (1ull << ibits) - 1ull;
+
+    // ---- phase A: candidate filter (:186 strict >) + score keys ------------------------------
+    int my = 0;
+    for (int64_t i = tid; i < N; i += NMS_T) {
+        const float s = bx[i * 6 + 1];
+        const bool c = s > conf_thr;
+        skey[i] = c ? desc_key(s) : 0xFFFFFFFFu;
+        my += c ? 1 : 0;
+    }
+    if (tid == 0) { L.s_nk = 0; L.s_done = 0; }
+    int remaining = block_sum(my, L.red);     // contains the barriers that publish skey to the block
+    unsigned long long lo_excl = 0ull;        // keys <= lo_excl are already consumed
+    int nk_seen = 0;
+
+    while (remaining > 0 && nk_seen < max_det) {
+        // ---- select T = the need-th smallest unconsumed key (radix select, 11-bit digits) -----
+        const int need0 = remaining < NMS_CAP ? remaining : NMS_CAP;
+        unsigned long long T;
+        if (remaining <= NMS_CAP) {
+            T = ~0ull;
+        } else {
+            unsigned long long prefix = 0ull;
+            int pbits = 0;
+            unsigned need = (unsigned)need0;
+            bool early = false;
+            while (pbits < kbits) {
+                const int w = (kbits - pbits) < NMS_HBITS ? (kbits - pbits) : NMS_HBITS;
+                const int rest = kbits - pbits - w;
+                for (int i = tid; i < NMS_HBINS; i += NMS_T) L.hist[i] = 0u;
+                __syncthreads();
+                for (int64_t i = tid; i < N; i += NMS_T) {
+                    const unsigned k32 = skey[i];
+                    if (k32 == 0xFFFFFFFFu) continue;
+                    const unsigned long long k = ((unsigned long long)k32 << ibits) | (unsigned long long)i;
+                    if (k <= lo_excl) continue;
+                    if (pbits > 0 && (k >> (kbits - pbits)) != prefix) continue;
+                    atomicAdd(&L.hist[(unsigned)((k >> rest) & ((1ull << w) - 1ull))], 1u);
+                }
+                __syncthreads();
+                if (wid == 0) {
+                    // lane l owns bins [l*32, l*32+32)
+                    unsigned s = 0;
+                    for (int q = 0; q < NMS_HBINS / 64; ++q) s += L.hist[lane * (NMS_HBINS / 64) + q];
+                    unsigned incl = s;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned v = __shfl_up(incl, o, 64);
+                        if (lane >= o) incl += v;
+                    }
+                    const unsigned excl = incl - s;
+                    if (excl < need && need <= incl) {
+                        unsigned cum = excl;
+                        for (int q = 0; q < NMS_HBINS / 64; ++q) {
+                            const unsigned hcount = L.hist[lane * (NMS_HBINS / 64) + q];
+                            if (cum + hcount >= need) {
+                                L.s_digit = (unsigned)(lane * (NMS_HBINS / 64) + q);
+                                L.s_need = need - cum;
+                                L.s_done = (cum + hcount == need) ? 1 : 0;
+                                break;
+                            }
+                            cum += hcount;
+                        }
+                    }
+                }
+                __syncthreads();
+                prefix = (prefix << w) | (unsigned long long)L.s_digit;
+                pbits += w;
+                need = L.s_need;
+                const int done = L.s_done;
+                __syncthreads();
+                if (done) { early = true; break; }
+            }
+            // early: the whole bucket `prefix` is taken -> every completion of the low bits
+            T = early && pbits < kbits ? ((prefix << (kbits - pbits)) | ((1ull << (kbits - pbits)) - 1ull)) : prefix;
+        }
+        // ---- gather the chunk (lo_excl, T] into LDS and sort it ---------------------------------
+        if (tid == 0) L.s_m = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < N; i += NMS_T) {
+            const unsigned k32 = skey[i];
+            if (k32 == 0xFFFFFFFFu) continue;
+            const unsigned long long k = ((unsigned long long)k32 << ibits) | (unsigned long long)i;
+            if (k > lo_excl && k <= T) {
+                const int pos = atomicAdd(&L.s_m, 1);
+                if (pos < NMS_CAP) L.keys[pos] = k;
+            }
+        }
+        __syncthreads();
+        const int m = L.s_m < NMS_CAP ? L.s_m : NMS_CAP;
+        int n2 = 64;
+        while (n2 < m) n2 <<= 1;
+        for (int i = m + tid; i < n2; i += NMS_T) L.keys[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (n2 >> 1); t += NMS_T) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int p = i | j;
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = L.keys[i], b = L.keys[p];
+                    if ((a > b) == up) { L.keys[i] = b; L.keys[p] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- greedy scan of the sorted chunk ---------------------------------------------------
+        for (int base = 0; base < m; base += NMS_T) {
+            const int nk0 = L.s_nk;
+            const int ci = base + tid;
+            const bool valid = ci < m;
+            NmsBox cb = {0.f, 0.f, 0.f, 0.f, 0.f};
+            int src = 0;
+            if (valid) {
+                src = (int)(L.keys[ci] & imask);
+                float cls, sc, x1, y1, x2, y2;
+                nms_load(bx + (int64_t)src * 6, cls, sc, x1, y1, x2, y2, cb);
+            }
+            bool alive = valid;
+            for (int k = 0; k < nk0 && alive; ++k) {
+                if (nms_suppresses(L.kbox[4 * k], L.kbox[4 * k + 1], L.kbox[4 * k + 2], L.kbox[4 * k + 3],
+                                   L.karea[k], cb, iou_thr))
+                    alive = false;
+            }
+            const unsigned long long bal = __ballot(alive);
+            if (lane == 0) L.wave_tot[wid] = __popcll(bal);
+            __syncthreads();
+            int wbase = 0, ns = 0;
+#pragma unroll
+            for (int q = 0; q < NMS_T / 64; ++q) {
+                const int c = L.wave_tot[q];
+                if (q < wid) wbase += c;
+                ns += c;
+            }
+            if (alive) {
+                const int pos = wbase + __popcll(bal & ((1ull << lane) - 1ull));
+                L.sbox[4 * pos] = cb.x1; L.sbox[4 * pos + 1] = cb.y1;
+                L.sbox[4 * pos + 2] = cb.x2; L.sbox[4 * pos + 3] = cb.y2;
+                L.sarea[pos] = cb.area;
+                L.sidx[pos] = src;
+            }
+            __syncthreads();
+            if (wid == 0) {
+                volatile float* kbox = L.kbox;
+                volatile float* karea = L.karea;
+                int nk = nk0;
+                for (int sb = 0; sb < ns && nk < max_det; sb += 64) {
+                    const int j = sb + lane;
+                    bool al = j < ns;
+                    NmsBox mb = {0.f, 0.f, 0.f, 0.f, 0.f};
+                    int msrc = 0;
+                    if (al) {
+                        mb.x1 = L.sbox[4 * j]; mb.y1 = L.sbox[4 * j + 1];
+                        mb.x2 = L.sbox[4 * j + 2]; mb.y2 = L.sbox[4 * j + 3];
+                        mb.area = L.sarea[j];
+                        msrc = L.sidx[j];
+                    }
+                    // boxes kept earlier in THIS group (after the block-wide test above)
+                    for (int k = nk0; k < nk && al; ++k) {
+                        if (nms_suppresses(kbox[4 * k], kbox[4 * k + 1], kbox[4 * k + 2], kbox[4 * k + 3],
+                                           karea[k], mb, iou_thr))
+                            al = false;
+                    }
+                    unsigned long long mask = __ballot(al);
+                    while (mask != 0ull && nk < max_det) {
+                        const int i = __ffsll((long long)mask) - 1;
+                        const float ix1 = __shfl(mb.x1, i, 64), iy1 = __shfl(mb.y1, i, 64);
+                        const float ix2 = __shfl(mb.x2, i, 64), iy2 = __shfl(mb.y2, i, 64);
+                        const float ia = __shfl(mb.area, i, 64);
+                        if (lane == i) {
+                            kbox[4 * nk] = ix1; kbox[4 * nk + 1] = iy1;
+                            kbox[4 * nk + 2] = ix2; kbox[4 * nk + 3] = iy2;
+                            karea[nk] = ia;
+                            float cls, sc, x1, y1, x2, y2;
+                            NmsBox tmp;
+                            nms_load(bx + (int64_t)msrc * 6, cls, sc, x1, y1, x2, y2, tmp);
+                            float* o = orow + (int64_t)nk * 6;
+                            o[0] = cls; o[1] = sc; o[2] = x1; o[3] = y1; o[4] = x2; o[5] = y2;
+                            oidx[nk] = msrc;
+                            al = false;
+                        }
+                        ++nk;
+                        if (al && lane > i && nms_suppresses(ix1, iy1, ix2, iy2, ia, mb, iou_thr)) al = false;
+                        mask = __ballot(al);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) L.s_nk = nk;
+            }
+            __syncthreads();
+            if (L.s_nk >= max_det) break;
+        }
+        nk_seen = L.s_nk;
+        lo_excl = T;
+        remaining -= m;
+        __syncthreads();
+    }
+    if (tid == 0) out_count[img] = L.s_nk;
+}
+
+extern "C" size_t y5m_nms_workspace_bytes(int B, int64_t N) {
+    return y5m_align((size_t)(B > 0 ? B : 0) * (size_t)(N > 0 ? N : 0) * sizeof(unsigned)) + 256;
+}
+
+extern "C" int y5m_nms(const float* boxes, int B, int64_t N, float conf_threshold, double iou_threshold,
+                       int max_det, float* out_rows, int32_t* out_idx, int32_t* out_count, void* ws,
+                       size_t ws_bytes, void* stream) {
+    Y5M_REQUIRE(B >= 0 && N >= 0, "bad dims");
+    Y5M_REQUIRE(max_det >= 1 && max_det <= NMS_MAXK, "max_det must be in [1,1024]");
+    Y5M_REQUIRE(N < (1ll << 31), "N too large");
+    if (B == 0) return Y5M_OK;
+    if (ws_bytes < y5m_nms_workspace_bytes(B, N)) { y5m_set_error("nms workspace too small"); return Y5M_EWS; }
+    int ibits = 1;
+    while ((1ll << ibits) < N) ++ibits;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsLds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)B), dim3(NMS_T), sizeof(NmsLds), y5m_stream(stream),
+                       boxes, N, conf_threshold, iou_threshold, max_det, ibits, out_rows, out_idx, out_count,
+                       reinterpret_cast<unsigned*>(ws));
+    Y5M_CHECK_LAUNCH("nms_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// IoU / GIoU entry points (reference utils/bboxes_utils.py:33-87)
+// =================================================================================================
+__global__ void iou_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int giou,
+                           float eps, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 qa = reinterpret_cast<const float4*>(a)[i], qb = reinterpret_cast<const float4*>(b)[i];
+    const float A[4] = {qa.x, qa.y, qa.z, qa.w}, Bv[4] = {qb.x, qb.y, qb.z, qb.w};
+    out[i] = box_iou_fwd(A, Bv, giou != 0, eps).out;
+}
+
+__global__ void iou_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                               const float* __restrict__ gout, int64_t n, int giou, float eps,
+                               float* __restrict__ ga, float* __restrict__ gb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 qa = reinterpret_cast<const float4*>(a)[i], qb = reinterpret_cast<const float4*>(b)[i];
+    const float A[4] = {qa.x, qa.y, qa.z, qa.w}, Bv[4] = {qb.x, qb.y, qb.z, qb.w};
+    const BoxFwd r = box_iou_fwd(A, Bv, giou != 0, eps);
+    float da[4], db[4];
+    box_iou_bwd(r, giou != 0, gout[i], da, db);
+    if (ga) reinterpret_cast<float4*>(ga)[i] = make_float4(da[0], da[1], da[2], da[3]);
+    if (gb) reinterpret_cast<float4*>(gb)[i] = make_float4(db[0], db[1], db[2], db[3]);
+}
+
+extern "C" int y5m_iou(const float* a, const float* b, int64_t n, int giou, float eps, float* out, void* stream) {
+    if (n <= 0) return Y5M_OK;
+    hipLaunchKernelGGL(iou_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, y5m_stream(stream), a, b, n,
+                       giou, eps, out);
+    Y5M_CHECK_LAUNCH("iou_kernel");
+    return Y5M_OK;
+}
+
+extern "C" int y5m_iou_bwd(const float* a, const float* b, const float* gout, int64_t n, int giou, float eps,
+                           float* ga, float* gb, void* stream) {
+    if (n <= 0) return Y5M_OK;
+    hipLaunchKernelGGL(iou_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, y5m_stream(stream), a, b,
+                       gout, n, giou, eps, ga, gb);
+    Y5M_CHECK_LAUNCH("iou_bwd_kernel");
+    return Y5M_OK;
+}

@@ -1,0 +1,393 @@
+// ComputeLoss for gfx950: build_targets (bit-exact) + fused loss forward/backward.
+// Restates reference ultralytics_loss.py:60-311. Compiled with -ffp-contract=off.
+#include "y5m_box.h"
+
+#define BT_T 1024
+
+struct BtOut {
+    int32_t* count[3];
+    int32_t* bagg[3];
+    float* tbox[3];
+    float* anch[3];
+    int32_t* tcls[3];
+};
+
+__device__ __forceinline__ float tmax(float a, float b) {   // torch.max: NaN propagates
+    return (isnan(a) || isnan(b)) ? __int_as_float(0x7fc00000) : fmaxf(a, b);
+}
+__device__ __forceinline__ float py_mod1(float a) {          // torch `% 1` (remainder, sign of divisor)
+    float r = fmodf(a, 1.0f);
+    if (r != 0.0f && r < 0.0f) r += 1.0f;
+    return r;
+}
+
+// ordered block compaction: returns the exclusive rank of this thread among flagged threads and the
+// block total; contains two barriers.
+__device__ __forceinline__ int block_rank(bool flag, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    if (lane == 0) wave_tot[wid] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0;
+    total = 0;
+#pragma unroll
+    for (int q = 0; q < BT_T / 64; ++q) {
+        const int c = wave_tot[q];
+        if (q < wid) wbase += c;
+        total += c;
+    }
+    __syncthreads();
+    return wbase + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+// One workgroup per scale. Row order: offset-major [0,0],[.5,0],[0,.5],[-.5,0],[0,-.5];
+// inside an offset block: anchor-major, then original target order.
+__global__ __launch_bounds__(BT_T) void build_targets_kernel(
+    const float* __restrict__ targets, int nt_static, const int32_t* __restrict__ d_nt, int nt_max,
+    const float* __restrict__ anchors, int naxs, int ny0, int ny1, int ny2, int nx0, int nx1, int nx2,
+    float anchor_t, BtOut out, int32_t* __restrict__ frow_ws) {
+    __shared__ int wave_tot[BT_T / 64];
+    const int s = blockIdx.x;
+    const int ny = s == 0 ? ny0 : (s == 1 ? ny1 : ny2);
+    const int nx = s == 0 ? nx0 : (s == 1 ? nx1 : nx2);
+    int nt = d_nt ? *d_nt : nt_static;
+    if (nt > nt_max) nt = nt_max;
+    const float* anc = anchors + s * naxs * 2;
+    int32_t* frow = frow_ws + (size_t)s * naxs * nt_max;
+    const float fnx = (float)nx, fny = (float)ny;
+    const float g = 0.5f;
+    const int tid = threadIdx.x;
+
+    // stage 1: anchor-ratio filter (:186-213), ordered compaction -> frow
+    int nf = 0;
+    const int nrow = naxs * nt;
+    for (int r0 = 0; r0 < nrow; r0 += BT_T) {
+        const int r = r0 + tid;
+        bool pass = false;
+        if (r < nrow) {
+            const int a = r / nt, i = r - a * nt;
+            const float gw = targets[6 * i + 4] * fnx, gh = targets[6 * i + 5] * fny;   // t = targets*gain
+            const float rw = gw / anc[2 * a], rh = gh / anc[2 * a + 1];                 // :190
+            const float m = tmax(tmax(rw, 1.0f / rw), tmax(rh, 1.0f / rh));            // :199
+            pass = m < anchor_t;
+        }
+        int total;
+        const int rank = block_rank(pass, wave_tot, total);
+        if (pass) frow[nf + rank] = r;
+        nf += total;
+    }
+    __syncthreads();   // frow visible block-wide (global writes drained by the barrier)
+
+    // stage 2: neighbour offsets (:222-255) and outputs
+    int n = 0;
+    for (int o = 0; o < 5; ++o) {
+        for (int q0 = 0; q0 < nf; q0 += BT_T) {
+            const int q = q0 + tid;
+            bool take = false;
+            int a = 0, i = 0;
+            float gx = 0.f, gy = 0.f;
+            if (q < nf) {
+                const int r = frow[q];
+                a = r / nt; i = r - a * nt;
+                gx = targets[6 * i + 2] * fnx;
+                gy = targets[6 * i + 3] * fny;
+                const float gxi = fnx - gx, gyi = fny - gy;                              // :219
+                switch (o) {
+                    case 0: take = true; break;
+                    case 1: take = (py_mod1(gx) < g) && (gx > 1.0f); break;              // j  :225
+                    case 2: take = (py_mod1(gy) < g) && (gy > 1.0f); break;              // k
+                    case 3: take = (py_mod1(gxi) < g) && (gxi > 1.0f); break;            // l  :235
+                    default: take = (py_mod1(gyi) < g) && (gyi > 1.0f); break;           // m
+                }
+            }
+            int total;
+            const int rank = block_rank(take, wave_tot, total);
+            if (take) {
+                const int pos = n + rank;
+                const float ox = (o == 1 ? 1.0f : (o == 3 ? -1.0f : 0.0f)) * g;
+                const float oy = (o == 2 ? 1.0f : (o == 4 ? -1.0f : 0.0f)) * g;
+                int gi = (int)(gx - ox);                                                 // .long() :278
+                int gj = (int)(gy - oy);
+                gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);                           // clamp_ :285
+                gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);
+                reinterpret_cast<int4*>(out.bagg[s])[pos] =
+                    make_int4((int)targets[6 * i + 0], a, gj, gi);
+                reinterpret_cast<float4*>(out.tbox[s])[pos] =
+                    make_float4(gx - (float)gi, gy - (float)gj, targets[6 * i + 4] * fnx, targets[6 * i + 5] * fny);
+                reinterpret_cast<float2*>(out.anch[s])[pos] = make_float2(anc[2 * a], anc[2 * a + 1]);
+                out.tcls[s][pos] = (int)targets[6 * i + 1];
+            }
+            n += total;
+        }
+    }
+    if (tid == 0) *out.count[s] = n;
+}
+
+extern "C" size_t y5m_build_targets_workspace_bytes(int nt_max, int naxs) {
+    return y5m_align((size_t)3 * (size_t)naxs * (size_t)(nt_max > 0 ? nt_max : 1) * sizeof(int32_t)) + 256;
+}
+
+extern "C" int y5m_build_targets(const float* targets, int nt, const int32_t* d_nt, int nt_max,
+                                 const float* anchors, int naxs, const int* ny, const int* nx, float anchor_t,
+                                 y5m_targets out[3], void* ws, size_t ws_bytes, void* stream) {
+    Y5M_REQUIRE(naxs >= 1 && nt_max >= 0 && nt >= 0, "bad dims");
+    Y5M_REQUIRE(nt <= nt_max || d_nt, "nt exceeds nt_max");
+    if (ws_bytes < y5m_build_targets_workspace_bytes(nt_max, naxs)) { y5m_set_error("build_targets ws too small"); return Y5M_EWS; }
+    BtOut o;
+    for (int s = 0; s < 3; ++s) {
+        o.count[s] = out[s].count; o.bagg[s] = out[s].bagg; o.tbox[s] = out[s].tbox;
+        o.anch[s] = out[s].anch; o.tcls[s] = out[s].tcls;
+    }
+    hipLaunchKernelGGL(build_targets_kernel, dim3(3), dim3(BT_T), 0, y5m_stream(stream), targets, nt, d_nt,
+                       nt_max, anchors, naxs, ny[0], ny[1], ny[2], nx[0], nx[1], nx[2], anchor_t, o,
+                       reinterpret_cast<int32_t*>(ws));
+    Y5M_CHECK_LAUNCH("build_targets_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// loss forward + backward (reference ultralytics_loss.py:60-120)
+// =================================================================================================
+struct LossScale {
+    const float* p;        // logits (B,naxs,ny,nx,nch)
+    float* grad;           // same shape or NULL
+    const int32_t* count;
+    const int32_t* bagg;
+    const float* tbox;
+    const float* anch;
+    const int32_t* tcls;
+    int32_t* owner;        // [cells] last row index that targets the cell, -1 = none
+    float* rowiou;         // [cap] clamp(giou,0)
+    float* rowlbox;        // [cap] 1 - giou
+    float* rowcls;         // [cap] sum_c bce
+    float* objpart;        // [nblk] per-block partial sums of the objectness BCE
+    int ny, nx, cap, nblk;
+    int64_t cells;
+    float balance;
+};
+struct LossArgs {
+    LossScale s[3];
+    int B, naxs, nc, nch;
+    float lam_box, lam_obj, lam_cls;
+};
+
+__device__ __forceinline__ float bce_logits(float x, float t) {   // BCEWithLogits, pos_weight = 1
+    return fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+// one wave per target row. BWD=false: forward partials + tobj ownership; BWD=true: gradients.
+template <bool BWD>
+__global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs A) {
+    const LossScale& S = A.s[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = *S.count;
+    if (j >= n) return;
+    const int4 q = reinterpret_cast<const int4*>(S.bagg)[j];
+    const int64_t cell = (((int64_t)q.x * A.naxs + q.y) * S.ny + q.z) * S.nx + q.w;
+    const float* row = S.p + cell * A.nch;
+    const float v0 = lane < A.nch ? row[lane] : 0.0f;
+    const float v1 = lane + 64 < A.nch ? row[lane + 64] : 0.0f;
+    const float l0 = __shfl(v0, 0, 64), l1 = __shfl(v0, 1, 64), l2 = __shfl(v0, 2, 64), l3 = __shfl(v0, 3, 64);
+    const float2 an = reinterpret_cast<const float2*>(S.anch)[j];
+    const float4 tb = reinterpret_cast<const float4*>(S.tbox)[j];
+    const float s0 = sigmoidf_(l0), s1 = sigmoidf_(l1), s2 = sigmoidf_(l2), s3 = sigmoidf_(l3);
+    float pb[4], tbv[4] = {tb.x, tb.y, tb.z, tb.w};
+    pb[0] = s0 * 2.0f - 0.5f;                         // :81
+    pb[1] = s1 * 2.0f - 0.5f;
+    const float e2 = s2 * 2.0f, e3 = s3 * 2.0f;
+    pb[2] = (e2 * e2) * an.x;                         // :82
+    pb[3] = (e3 * e3) * an.y;
+    const BoxFwd r = box_iou_fwd(pb, tbv, true, 1e-7f);
+    const int tc = S.tcls[j];
+    if (!BWD) {
+        float c = 0.0f;
+        if (lane >= 5 && lane < A.nch) c += bce_logits(v0, (lane - 5) == tc ? 1.0f : 0.0f);
+        if (lane + 64 < A.nch) c += bce_logits(v1, (lane + 59) == tc ? 1.0f : 0.0f);
+        c = wave_sum(c);
+        if (lane == 0) {
+            S.rowlbox[j] = 1.0f - r.out;              // :85
+            S.rowiou[j] = r.out < 0.0f ? 0.0f : r.out;   // :88 detach().clamp(0)
+            S.rowcls[j] = c;
+            atomicMax(&S.owner[cell], j);             // :89 last row wins (CPU index_put order)
+        }
+    } else {
+        float* grow = S.grad + cell * A.nch;
+        const float bs = (float)A.B;
+        const float gg = -(A.lam_box * bs) / (float)n;          // d loss / d giou_j
+        const float gc = (A.lam_cls * bs) / ((float)n * (float)A.nc);
+        if (lane == 0) {
+            float ga[4], gb[4];
+            box_iou_bwd(r, true, gg, ga, gb);
+            atomicAdd(&grow[0], ga[0] * 2.0f * s0 * (1.0f - s0));
+            atomicAdd(&grow[1], ga[1] * 2.0f * s1 * (1.0f - s1));
+            atomicAdd(&grow[2], ga[2] * an.x * 8.0f * s2 * s2 * (1.0f - s2));
+            atomicAdd(&grow[3], ga[3] * an.y * 8.0f * s3 * s3 * (1.0f - s3));
+        }
+        if (A.nc > 1) {
+            if (lane >= 5 && lane < A.nch)
+                atomicAdd(&grow[lane], (sigmoidf_(v0) - ((lane - 5) == tc ? 1.0f : 0.0f)) * gc);
+            if (lane + 64 < A.nch)
+                atomicAdd(&grow[lane + 64], (sigmoidf_(v1) - ((lane + 59) == tc ? 1.0f : 0.0f)) * gc);
+        }
+    }
+}
+
+// objectness BCE over every cell of a scale + (optional) full overwrite of the gradient tensor:
+// zeros everywhere, d/d(obj logit) in channel 4. One wave owns 64 consecutive cells so the gradient
+// rows are written as one contiguous, coalesced run.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A) {
+    __shared__ float red[4];
+    __shared__ float gsm[4][64];
+    const LossScale& S = A.s[blockIdx.y];
+    if ((int)blockIdx.x >= S.nblk) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
+    const int64_t cell = c0 + lane;
+    float bce = 0.0f, gobj = 0.0f;
+    if (cell < S.cells) {
+        const float x = S.p[cell * A.nch + 4];
+        const int ow = S.owner[cell];
+        const float t = ow >= 0 ? S.rowiou[ow] : 0.0f;
+        bce = bce_logits(x, t);                                          // :101
+        gobj = (sigmoidf_(x) - t) * (S.balance * A.lam_obj * (float)A.B / (float)S.cells);
+    }
+    if (GRAD) {
+        gsm[wid][lane] = gobj;                       // same-wave LDS traffic is in order: no barrier
+        if (c0 < S.cells) {
+            const int ncell = (int)((S.cells - c0) < 64 ? (S.cells - c0) : 64);
+            const int nelem = ncell * A.nch;
+            float* dst = S.grad + c0 * A.nch;
+            const volatile float* gl = gsm[wid];
+            if ((((uintptr_t)dst) & 15) == 0) {
+                const int nvec = nelem >> 2;
+                for (int v = lane; v < nvec; v += 64) {
+                    const int e = 4 * v;
+                    const int cl = e / A.nch, ch = e - cl * A.nch;
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int k = 4 - ch;             // position of channel 4 inside this vector
+                    if (k >= 0 && k < 4) {
+                        const float go = gl[cl];
+                        if (k == 0) w.x = go; else if (k == 1) w.y = go; else if (k == 2) w.z = go; else w.w = go;
+                    }
+                    reinterpret_cast<float4*>(dst)[v] = w;
+                }
+                for (int e = (nvec << 2) + lane; e < nelem; e += 64) {
+                    const int cl = e / A.nch, ch = e - cl * A.nch;
+                    dst[e] = ch == 4 ? gl[cl] : 0.0f;
+                }
+            } else {
+                for (int e = lane; e < nelem; e += 64) {
+                    const int cl = e / A.nch, ch = e - cl * A.nch;
+                    dst[e] = ch == 4 ? gl[cl] : 0.0f;
+                }
+            }
+        }
+    }
+    bce = wave_sum(bce);
+    if (lane == 0) red[wid] = bce;
+    __syncthreads();
+    if (threadIdx.x == 0) S.objpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ float block_sum_f(const float* __restrict__ v, int n, float* sm) {
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += v[i];
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float t = 0.0f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+    return t;
+}
+
+// deterministic final reduction (fixed tree), single workgroup
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(LossArgs A, float* __restrict__ loss_out) {
+    __shared__ float sm[16];
+    float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
+    for (int s = 0; s < 3; ++s) {
+        const LossScale& S = A.s[s];
+        const int n = *S.count;
+        if (n > 0) {
+            lbox += block_sum_f(S.rowlbox, n, sm) / (float)n;                    // :85 mean
+            if (A.nc > 1) lcls += block_sum_f(S.rowcls, n, sm) / ((float)n * (float)A.nc);   // :95
+        }
+        lobj += (block_sum_f(S.objpart, S.nblk, sm) / (float)S.cells) * S.balance;            // :101-102
+    }
+    if (threadIdx.x == 0) {
+        lbox *= A.lam_box; lobj *= A.lam_obj; lcls *= A.lam_cls;                 // :104-106
+        loss_out[0] = (lbox + lobj + lcls) * (float)A.B;                         // :120
+        loss_out[1] = lbox; loss_out[2] = lobj; loss_out[3] = lcls;
+    }
+}
+
+static size_t loss_ws_layout(int B, int naxs, const int* ny, const int* nx, int nt_max, size_t off[3][5], int nblk[3]) {
+    size_t cur = 0;
+    const size_t cap = (size_t)5 * naxs * (nt_max > 0 ? nt_max : 1);
+    for (int s = 0; s < 3; ++s) {
+        const size_t cells = (size_t)B * naxs * ny[s] * nx[s];
+        nblk[s] = (int)((cells + 255) / 256);
+        off[s][0] = cur; cur += y5m_align(cells * 4);
+        off[s][1] = cur; cur += y5m_align(cap * 4);
+        off[s][2] = cur; cur += y5m_align(cap * 4);
+        off[s][3] = cur; cur += y5m_align(cap * 4);
+        off[s][4] = cur; cur += y5m_align((size_t)(nblk[s] > 0 ? nblk[s] : 1) * 4);
+    }
+    return cur + 256;
+}
+
+extern "C" size_t y5m_compute_loss_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int nt_max) {
+    size_t off[3][5]; int nblk[3];
+    return loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
+}
+
+extern "C" int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int naxs, const int* ny,
+                                const int* nx, int nc, const y5m_targets tg[3], int nt_max,
+                                const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    Y5M_REQUIRE(B >= 1 && naxs >= 1 && nc >= 1, "bad dims");
+    Y5M_REQUIRE(5 + nc <= 128, "5+nc must be <= 128 (one wave holds a logit row in two registers)");
+    size_t off[3][5]; int nblk[3];
+    const size_t need = loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
+    if (ws_bytes < need) { y5m_set_error("compute_loss ws too small"); return Y5M_EWS; }
+    hipStream_t st = y5m_stream(stream);
+    char* w = reinterpret_cast<char*>(ws);
+    LossArgs A;
+    A.B = B; A.naxs = naxs; A.nc = nc; A.nch = 5 + nc;
+    A.lam_box = lambda_box; A.lam_obj = lambda_obj; A.lam_cls = lambda_cls;
+    const bool want_grad = grad && grad[0] && grad[1] && grad[2];
+    int max_blk = 0;
+    const int cap = 5 * naxs * (nt_max > 0 ? nt_max : 1);
+    for (int s = 0; s < 3; ++s) {
+        LossScale& S = A.s[s];
+        S.p = p[s]; S.grad = want_grad ? grad[s] : nullptr;
+        S.count = tg[s].count; S.bagg = tg[s].bagg; S.tbox = tg[s].tbox; S.anch = tg[s].anch; S.tcls = tg[s].tcls;
+        S.owner = reinterpret_cast<int32_t*>(w + off[s][0]);
+        S.rowiou = reinterpret_cast<float*>(w + off[s][1]);
+        S.rowlbox = reinterpret_cast<float*>(w + off[s][2]);
+        S.rowcls = reinterpret_cast<float*>(w + off[s][3]);
+        S.objpart = reinterpret_cast<float*>(w + off[s][4]);
+        S.ny = ny[s]; S.nx = nx[s]; S.cap = cap; S.nblk = nblk[s];
+        S.cells = (int64_t)B * naxs * ny[s] * nx[s];
+        S.balance = balance[s];
+        max_blk = nblk[s] > max_blk ? nblk[s] : max_blk;
+        if (hipMemsetAsync(S.owner, 0xFF, (size_t)S.cells * 4, st) != hipSuccess) { y5m_set_error("memset owner"); return Y5M_ELAUNCH; }
+    }
+    const dim3 rgrid((unsigned)((cap + 3) / 4), 3);
+    if (nt_max > 0) {
+        hipLaunchKernelGGL(loss_rows_kernel<false>, rgrid, dim3(256), 0, st, A);
+        Y5M_CHECK_LAUNCH("loss_rows_kernel<fwd>");
+    }
+    if (want_grad) hipLaunchKernelGGL(loss_obj_kernel<true>, dim3((unsigned)max_blk, 3), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(loss_obj_kernel<false>, dim3((unsigned)max_blk, 3), dim3(256), 0, st, A);
+    Y5M_CHECK_LAUNCH("loss_obj_kernel");
+    if (want_grad && nt_max > 0) {
+        hipLaunchKernelGGL(loss_rows_kernel<true>, rgrid, dim3(256), 0, st, A);
+        Y5M_CHECK_LAUNCH("loss_rows_kernel<bwd>");
+    }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, A, loss_out);
+    Y5M_CHECK_LAUNCH("loss_finalize_kernel");
+    return Y5M_OK;
+}
