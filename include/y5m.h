@@ -112,6 +112,118 @@ int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int n
                      const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
                      float* loss_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Model (model.py): Conv-BN-SiLU building blocks. Activations are (ptr, ld) NHWC, dtype per call.
+ * ------------------------------------------------------------------------------------------- */
+
+#define Y5M_EPI_RAW_STATS 0   /* store raw conv output (+ per-tile channel sum / sum-of-squares)  */
+#define Y5M_EPI_AFFINE_ACT 1  /* y*scale[n]+shift[n] -> act -> (+res): eval-mode folded BN         */
+#define Y5M_EPI_HEAD 2        /* + bias, f32 store permuted to (B,naxs,ny,nx,nch) (model.py:165-175) */
+#define Y5M_EPI_DGRAD 3       /* plain store or accumulate (data gradient)                           */
+
+/* One implicit-GEMM convolution launch: out[m][n] = sum_{tap,c} in[pix(m,tap)][c] * w[n][tap*Cin+c].
+ * Replaces nn.Conv2d of CBL (model.py:12-28) / HEADS (model.py:162) and, with transposed packed
+ * weights and mirrored tap offsets, its autograd data-gradient. */
+typedef struct {
+    const void* in;      /* activations (ptr, ldin)                                              */
+    const void* w;       /* packed weights [Np][Kp], K-contiguous, zero padded                   */
+    void* out;
+    int32_t B, Hin, Win, ldin;
+    int32_t Hg, Wg;      /* output grid enumerated by m = (b*Hg + gy)*Wg + gx                    */
+    int32_t sy, sx;      /* input y = gy*sy + dh(tap), x = gx*sx + dw(tap)                       */
+    int32_t th, tw;      /* tap grid; tap = ta*tw + tb                                           */
+    int32_t dh0, dhs, dw0, dws;   /* dh = dh0 + ta*dhs ; dw = dw0 + tb*dws                       */
+    int32_t Cin;         /* channels per tap (multiple of 16 bytes)                              */
+    int32_t K, Kp;       /* K = th*tw*Cin ; Kp = weight row stride (multiple of the K step)      */
+    int32_t N;           /* output channels                                                      */
+    int32_t M;           /* B*Hg*Wg                                                              */
+    int32_t Hout, Wout, ldout, osy, osx, ooy, oox;  /* out pixel (b, gy*osy+ooy, gx*osx+oox)      */
+    int32_t epi, act, accumulate;
+    const float* scale;  /* [N] scale (AFFINE_ACT) or bias (HEAD)                                */
+    const float* shift;  /* [N]                                                                  */
+    const void* res;     /* optional residual (same pixel placement as out)                      */
+    int32_t ldres;
+    float* stats;        /* RAW_STATS: [tiles_m][2][Np] partials, or NULL                        */
+    int32_t Np;          /* stats row stride >= roundup(N, y5m_conv_tile_n(N))                   */
+    int32_t naxs, nch;   /* HEAD                                                                 */
+    int32_t tiles_m, tiles_n;   /* filled by the library                                         */
+} y5m_conv_args;
+
+int y5m_conv_tile_n(int N);   /* channel tile (48 or 96) the library uses for N output channels */
+int y5m_conv(const y5m_conv_args* args, int dtype, void* stream);
+
+/* Weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
+ * dwgt[n][tap*C + c] += sum_m dy[m][n] * x[pix(m,tap)][c], f32 atomics into a ZEROED packed buffer. */
+typedef struct {
+    const void* dy;      /* [M][lddy] gradient wrt the conv output                               */
+    const void* x;       /* conv input activations (ptr, ldx)                                    */
+    float* dwgt;         /* packed f32 gradient [N][lddw]                                        */
+    int32_t B, Hin, Win, ldx;
+    int32_t Hg, Wg, sy, sx, th, tw, dh0, dhs, dw0, dws;   /* same meaning as y5m_conv_args       */
+    int32_t C;           /* input channels per tap                                               */
+    int32_t N;           /* output channels                                                      */
+    int32_t M, lddy, lddw;
+    int32_t ksplit;      /* pixel-range splits (<=0: library picks)                              */
+    int32_t tiles_n, tiles_c;   /* filled by the library                                         */
+} y5m_wgrad_args;
+int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
+
+/* Weight layout conversion. master f32 [Cout][Cin][KH][KW] (the reference state_dict layout,
+ * model.py:15) -> packed K-contiguous rows in compute dtype.
+ *   mode 0: forward rows  dst[co][(ta*tw+tb)*Cin + ci]   (kh = kh0+ta*khs, kw = kw0+tb*kws)
+ *   mode 1: dgrad rows    dst[ci][(ta*tw+tb)*Cout + co]
+ *   mode 2: stem 6x6/s2 on 3 channels as 3x3/s1 on the 2x2 space-to-depth input (12 -> 16 channels) */
+int y5m_pack_weights(const float* src, int Cout, int Cin, int KH, int KW, int mode, int kh0, int khs,
+                     int th, int kw0, int kws, int tw, void* dst, int rows_p, int Kp, int cstride,
+                     int dtype, void* stream);   /* cstride: per-tap channel stride (0 = dense) */
+/* packed f32 gradient [Cout][ldg] (mode 0 or 2 ordering) -> [Cout][Cin][KH][KW] */
+int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
+                     void* stream);
+/* images (B,3,H,W) f32 NCHW (model.py:210 input) -> (B,H/2,W/2,16) NHWC, ch=(dy*2+dx)*3+c */
+int y5m_s2d_input(const float* img, int B, int H, int W, void* out, int dtype, void* stream);
+
+/* BatchNorm2d(eps=1e-3, momentum=0.03) of CBL (model.py:17), training mode: finalise the batch
+ * statistics from the conv epilogue partials, update running stats (unbiased var), emit the fused
+ * scale/shift and the saved mean / invstd for backward. */
+int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, int64_t count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* mean_out, float* invstd_out, int update_running,
+                    void* stream);
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int y5m_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                float eps, int C, float* scale, float* shift, void* stream);
+/* out = act(y*scale+shift) (+ res): BN normalise + nn.SiLU (model.py:20) + Bottleneck add (:50) */
+int y5m_bn_act(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
+               void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream);
+/* autograd of the above: dgamma, dbeta (param grads) and dy given dz */
+size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C);
+int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+               const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
+               float* dbeta, int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes,
+               int dtype, void* stream);
+/* dst (+)= src on (ptr, ld) views: residual / concat gradient plumbing */
+int y5m_add(const void* src, int ldsrc, void* dst, int lddst, int64_t M, int C, int accumulate, int dtype,
+            void* stream);
+/* nearest x2 (model.py:225) and its backward */
+int y5m_upsample2x(const void* in, int ldin, int B, int H, int W, int C, void* out, int ldout, int dtype,
+                   void* stream);
+int y5m_upsample2x_bwd(const void* gout, int ldg, int B, int H, int W, int C, void* gin, int ldgin,
+                       int accumulate, int dtype, void* stream);
+/* SPPF (model.py:103-112): the three cascaded MaxPool2d(5,1,2) in one launch; backward per level */
+int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, int dtype,
+                  void* stream);
+int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
+                     int ldgin, int accumulate, int dtype, void* stream);
+/* d(loss)/d(logits) (B,naxs,ny,nx,nch) f32 -> head conv output gradient [B*ny*nx][ldp] + bias grad */
+int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
+                       float* dbias, int dtype, void* stream);
+/* optimizer (train.py:61 Adam(lr, weight_decay) + training_utils.py:118 clip_grad_norm_(10)) */
+size_t y5m_adam_workspace_bytes(void);
+int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, void* stream);
+int y5m_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm, float max_norm,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_step,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

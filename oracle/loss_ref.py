@@ -74,8 +74,14 @@ def compute_loss_ultra(p, targets, anchors, nc=80):
             iou = giou(pbox, torch.from_numpy(d["tbox"]), GIoU=True).squeeze(-1)
             lbox = lbox + (1.0 - iou).mean()
             iou_d = iou.detach().clamp(0).type(tobj.dtype)
-            # non-accumulating index_put: on CPU the LAST row wins for duplicate cells
-            tobj[b, a, gj, gi] = iou_d
+            # non-accumulating index_put (:89). For duplicate cells the reference's outcome is the LAST
+            # row whenever ATen runs index_put_ serially (n below its parallel grain, or 1 thread:
+            # measured); with several threads and n >~ 1000 ATen races and the winner is arbitrary.
+            # The oracle pins the deterministic serial semantics: last row wins.
+            cell = ((d["b"] * pi.shape[1] + d["a"]) * pi.shape[2] + d["gj"]) * pi.shape[3] + d["gi"]
+            _, first_rev = np.unique(cell[::-1], return_index=True)
+            last = torch.from_numpy((n - 1 - first_rev).astype(np.int64))
+            tobj.view(-1)[torch.from_numpy(cell[last.numpy()].astype(np.int64))] = iou_d[last]
             if nc > 1:
                 t = torch.zeros_like(pcls)
                 t[range(n), torch.from_numpy(d["tcls"])] = 1

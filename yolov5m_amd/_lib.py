@@ -25,11 +25,27 @@ class Targets(ctypes.Structure):
                 ("tcls", c_void_p)]
 
 
-class ConvDesc(ctypes.Structure):
-    """mirror of y5m_conv (include/y5m.h)"""
-    _fields_ = [("B", c_int), ("Hi", c_int), ("Wi", c_int), ("Cin", c_int), ("ldin", c_int),
-                ("Ho", c_int), ("Wo", c_int), ("Cout", c_int), ("ldout", c_int),
-                ("k", c_int), ("s", c_int), ("p", c_int), ("dtype", c_int)]
+class ConvArgs(ctypes.Structure):
+    """mirror of y5m_conv_args (include/y5m.h) -- field order is the ABI"""
+    _fields_ = ([("inp", c_void_p), ("w", c_void_p), ("out", c_void_p)] +
+                [(n, c_int) for n in ("B", "Hin", "Win", "ldin", "Hg", "Wg", "sy", "sx", "th", "tw", "dh0", "dhs",
+                                      "dw0", "dws", "Cin", "K", "Kp", "N", "M", "Hout", "Wout", "ldout", "osy",
+                                      "osx", "ooy", "oox", "epi", "act", "accumulate")] +
+                [("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("ldres", c_int),
+                 ("stats", c_void_p), ("Np", c_int), ("naxs", c_int), ("nch", c_int), ("tiles_m", c_int),
+                 ("tiles_n", c_int)])
+
+
+class WgradArgs(ctypes.Structure):
+    """mirror of y5m_wgrad_args (include/y5m.h)"""
+    _fields_ = ([("dy", c_void_p), ("x", c_void_p), ("dwgt", c_void_p)] +
+                [(n, c_int) for n in ("B", "Hin", "Win", "ldx", "Hg", "Wg", "sy", "sx", "th", "tw", "dh0", "dhs",
+                                      "dw0", "dws", "C", "N", "M", "lddy", "lddw", "ksplit", "tiles_n", "tiles_c")])
+
+
+EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD, EPI_DGRAD = 0, 1, 2, 3
+ACT_NONE, ACT_SILU = 0, 1
+F32, BF16 = 0, 1
 
 
 _SIGS = {
@@ -53,6 +69,35 @@ _SIGS = {
     "y5m_compute_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                  c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
+    "y5m_conv_tile_n": (c_int, [c_int]),
+    "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),
+    "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),
+    "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "y5m_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "y5m_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "y5m_bn_act": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int,
+                           c_int, c_int, c_void_p]),
+    "y5m_bn_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "y5m_bn_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                           c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int,
+                           c_void_p]),
+    "y5m_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "y5m_upsample2x": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "y5m_upsample2x_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                   c_void_p]),
+    "y5m_sppf_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p]),
+    "y5m_maxpool5_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                 c_int, c_int, c_void_p]),
+    "y5m_head_grad_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p]),
+    "y5m_adam_workspace_bytes": (c_size_t, []),
+    "y5m_grad_norm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "y5m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
+                              c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

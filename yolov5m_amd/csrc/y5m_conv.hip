@@ -1,0 +1,281 @@
+// Implicit-GEMM convolution kernel (forward conv, fused epilogues, and data-gradient) for gfx950.
+// See y5m_conv.h for the tiling / layout description.
+#include "y5m_conv.h"
+
+#include <string.h>
+
+template <typename T, int WM, int WN, int MF, int NF>
+__global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams P) {
+    constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+    static_assert(BM == CV_BM && WM * WN == 4, "tile config");
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int NA = BM * 8 / CV_THREADS;                       // 16-byte chunks per thread (A)
+    constexpr int NB = (BN * 8 + CV_THREADS - 1) / CV_THREADS;    // (B)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid % WM, wn = wid / WM;
+
+    // XCD-aware tile order: blocks that share a pixel tile (same tile_m, different tile_n) get
+    // consecutive logical ids on ONE XCD so the activation tile is served from that XCD's L2.
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(P.in);
+    const T* __restrict__ W = reinterpret_cast<const T*>(P.w);
+
+    // ---- per-thread staging state ------------------------------------------------------------
+    const int q = tid & 7, r0 = tid >> 3;
+    int p0[NA], iy0[NA], ix0[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < P.M) {
+            const int gx = m % P.Wg;
+            const int t = m / P.Wg;
+            const int gy = t % P.Hg;
+            const int b = t / P.Hg;
+            iy0[i] = gy * P.sy;
+            ix0[i] = gx * P.sx;
+            p0[i] = (b * P.Hin + iy0[i]) * P.Win + ix0[i];
+        } else {
+            iy0[i] = -(1 << 28); ix0[i] = 0; p0[i] = 0;
+        }
+    }
+    // K position of this thread's chunk: kk = kt*BK + q*CH -> (tap row ta, tap col tb, channel c)
+    int c, ta, tb;
+    {
+        const int kk = q * CH;
+        const int tap = kk / P.Cin;
+        c = kk - tap * P.Cin;
+        ta = tap / P.tw;
+        tb = tap - ta * P.tw;
+    }
+    const T* wrow[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int r = r0 + 32 * i;
+        wrow[i] = W + (size_t)(n0 + (r < BN ? r : 0)) * P.Kp + q * CH;
+    }
+    uint4 ra[NA], rb[NB];
+    auto load_tile = [&](int kt) {
+        const int dh = P.dh0 + ta * P.dhs, dw = P.dw0 + tb * P.dws;
+        const bool kvalid = ta < P.th;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int iy = iy0[i] + dh, ix = ix0[i] + dw;
+            const bool v = kvalid && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            if (v) ra[i] = *reinterpret_cast<const uint4*>(X + (size_t)(p0[i] + dh * P.Win + dw) * P.ldin + c);
+            else ra[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (r0 + 32 * i < BN) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kt * BK);
+            else rb[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto advance_k = [&]() {
+        c += BK;
+        while (c >= P.Cin) {
+            c -= P.Cin;
+            if (++tb == P.tw) { tb = 0; ++ta; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + lds_off(r0 + 32 * i, q)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (r0 + 32 * i < BN) *reinterpret_cast<uint4*>(Bs + lds_off(r0 + 32 * i, q)) = rb[i];
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xa[MF], wb[NF];
+#pragma unroll
+            for (int b = 0; b < MF; ++b)
+                xa[b] = *reinterpret_cast<const uint4*>(As + lds_off(wm * MF * 16 + b * 16 + frow, 4 * ks + fq));
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+                wb[a] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * NF * 16 + a * 16 + frow, 4 * ks + fq));
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+#pragma unroll
+                for (int b = 0; b < MF; ++b) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, wb[a]), __builtin_bit_cast(bf16x8_t, xa[b]), acc[a][b], 0, 0, 0);
+                    } else {
+                        // 4 floats of a chunk feed 4 MFMAs; A and B use the same k permutation
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb[a].x), __uint_as_float(xa[b].x), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb[a].y), __uint_as_float(xa[b].y), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb[a].z), __uint_as_float(xa[b].z), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb[a].w), __uint_as_float(xa[b].w), acc[a][b], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // ---- main loop: register prefetch of tile kt+1 under the MFMAs of tile kt ------------------
+    const int nkt = P.Kp / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) { advance_k(); load_tile(kt + 1); }
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    // lane owns channels n = nb + a*16 + (lane>>4)*4 + {0..3} of pixel m = mb + b*16 + (lane&15)
+    const int nb = n0 + wn * NF * 16 + fq * 4;
+    const int mb = m0 + wm * MF * 16 + frow;
+
+    if (P.epi == EPI_RAW_STATS && P.stats) {
+        float* red = reinterpret_cast<float*>(smem);          // [2][WM][BN]; tiles are dead after the last barrier
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < MF; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float v = acc[a][b][r]; s[r] += v; ss[r] += v * v; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s[r] += __shfl_xor(s[r], o, 64); ss[r] += __shfl_xor(ss[r], o, 64); }
+            }
+            if (frow == 0) {
+                const int nl = wn * NF * 16 + a * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(0 * WM + wm) * BN + nl + r] = s[r];
+                    red[(1 * WM + wm) * BN + nl + r] = ss[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, nl = tid - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + nl];
+            P.stats[((size_t)tile_m * 2 + which) * P.Np + n0 + nl] = t;
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+        const int m = mb + b * 16;
+        if (m >= P.M) continue;
+        const int gx = m % P.Wg;
+        const int t = m / P.Wg;
+        const int gy = t % P.Hg;
+        const int bi = t / P.Hg;
+        const size_t opix = ((size_t)bi * P.Hout + (gy * P.osy + P.ooy)) * P.Wout + (gx * P.osx + P.oox);
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+            const int n = nb + a * 16;
+            if (n >= P.N) continue;
+            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (P.epi == EPI_HEAD) {
+                float* o = reinterpret_cast<float*>(P.out);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nn = n + r;
+                    if (nn < P.N) {
+                        const int an = nn / P.nch, cn = nn - an * P.nch;
+                        o[((((size_t)bi * P.naxs + an) * P.Hg + gy) * P.Wg + gx) * P.nch + cn] = v[r] + P.scale[nn];
+                    }
+                }
+                continue;
+            }
+            T* o = reinterpret_cast<T*>(P.out) + opix * P.ldout + n;
+            if (P.epi == EPI_AFFINE_ACT) {
+                const float4 sc = *reinterpret_cast<const float4*>(P.scale + n);
+                const float4 sh = *reinterpret_cast<const float4*>(P.shift + n);
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                if (P.act == Y5M_ACT_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+                }
+                if (P.res) {
+                    float rv[4];
+                    load4<T>(reinterpret_cast<const T*>(P.res) + opix * P.ldres + n, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+            } else if (P.epi == EPI_DGRAD && P.accumulate) {
+                float ov[4];
+                load4<T>(o, ov);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += ov[r];
+            }
+            store4<T>(o, v);
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int MF, int NF>
+static int launch_conv(ConvParams& P, hipStream_t st) {
+    constexpr int BN = WN * NF * 16;
+    P.tiles_m = (P.M + CV_BM - 1) / CV_BM;
+    P.tiles_n = (P.N + BN - 1) / BN;
+    const size_t lds = 2 * (size_t)(CV_BM + BN) * 128;
+    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(CV_THREADS), lds, st, P);
+    Y5M_CHECK_LAUNCH("conv_igemm_kernel");
+    return Y5M_OK;
+}
+
+extern "C" int y5m_conv_tile_n(int N) { return (N <= 48) ? 48 : 96; }
+
+extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
+    ConvParams P;
+    static_assert(sizeof(P) == sizeof(*args), "abi struct");
+    memcpy(&P, args, sizeof(P));
+    const int CH = dtype == Y5M_BF16 ? 8 : 4, BK = dtype == Y5M_BF16 ? 64 : 32;
+    Y5M_REQUIRE(dtype == Y5M_F32 || dtype == Y5M_BF16, "dtype");
+    Y5M_REQUIRE(P.Cin % CH == 0 && P.ldin % CH == 0, "Cin/ldin must be multiples of the 16-byte chunk");
+    Y5M_REQUIRE(P.Kp % BK == 0 && P.Kp >= P.K && P.K == P.th * P.tw * P.Cin, "K padding");
+    Y5M_REQUIRE(P.M == P.B * P.Hg * P.Wg && P.M > 0, "M");
+    Y5M_REQUIRE((int64_t)P.B * P.Hin * P.Win < (1ll << 31), "input pixel count overflows int32");
+    Y5M_REQUIRE(P.epi == EPI_HEAD || (P.N % 4 == 0 && P.ldout % 4 == 0), "N/ldout must be multiples of 4");
+    const int BN = y5m_conv_tile_n(P.N);
+    Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
+    hipStream_t st = y5m_stream(stream);
+    if (dtype == Y5M_BF16) {
+        if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
+        return launch_conv<bf16_t, 2, 2, 4, 3>(P, st);
+    } else {
+        if (BN == 48) return launch_conv<float, 4, 1, 2, 3>(P, st);
+        return launch_conv<float, 2, 2, 4, 3>(P, st);
+    }
+}

@@ -1,0 +1,692 @@
+// Non-GEMM kernels of the YOLOv5m train/infer step for gfx950: weight packing, input space-to-depth,
+// training-mode BatchNorm (statistics finalise, normalise+SiLU, backward), SPPF pooling, nearest
+// upsample, gradient plumbing and the fused clip+Adam optimizer. All HBM-bound: 16/32-byte vector
+// accesses along the channel axis of (ptr, ld) NHWC activations.
+#include "y5m_conv.h"
+
+#define EW_T 256
+template <typename T> struct Vec8 { float v[8]; };
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]) { load4<T>(p, v); load4<T>(p + 4, v + 4); }
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]) { store4<T>(p, v); store4<T>(p + 4, v + 4); }
+
+#define DISPATCH_T(dtype, ...)                                         \
+    if ((dtype) == Y5M_BF16) { using T = bf16_t; __VA_ARGS__ }        \
+    else if ((dtype) == Y5M_F32) { using T = float; __VA_ARGS__ }     \
+    else { y5m_set_error("bad dtype"); return Y5M_EINVAL; }
+
+static inline unsigned ew_blocks(int64_t n) { return (unsigned)((n + EW_T - 1) / EW_T); }
+
+// =================================================================================================
+// weight packing: master f32 [Cout][Cin][KH][KW] (reference state_dict layout) -> K-contiguous rows
+// =================================================================================================
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ src, int Cout, int Cin, int KH, int KW, int mode,
+                                    int kh0, int khs, int th, int kw0, int kws, int tw, T* __restrict__ dst,
+                                    int rows_p, int Kp, int cstride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows_p * Kp) return;
+    const int r = (int)(i / Kp), k = (int)(i - (int64_t)r * Kp);
+    float v = 0.0f;
+    if (mode == 2) {                       // stem: 6x6 s2 on 3ch == 3x3 s1 on space-to-depth 12(+4)ch
+        const int tap = k >> 4, cc = k & 15;
+        if (r < Cout && tap < 9 && cc < 12) {
+            const int a = tap / 3, b = tap - 3 * a;
+            const int dyx = cc / 3, c = cc - 3 * dyx;
+            const int dy = dyx >> 1, dx = dyx & 1;
+            v = src[((r * Cin + c) * KH + (2 * a + dy)) * KW + (2 * b + dx)];
+        }
+    } else {
+        const int Cc = mode == 0 ? Cin : Cout;      // channels per tap of the packed operand
+        const int Cs = cstride > 0 ? cstride : Cc;  // per-tap stride (>= Cc; the gap is zero padding)
+        const int R = mode == 0 ? Cout : Cin;
+        const int tap = k / Cs, cc = k - tap * Cs;
+        if (r < R && tap < th * tw && cc < Cc) {
+            const int ta = tap / tw, tb = tap - ta * tw;
+            const int kh = kh0 + ta * khs, kw = kw0 + tb * kws;
+            const int co = mode == 0 ? r : cc, ci = mode == 0 ? cc : r;
+            v = src[((co * Cin + ci) * KH + kh) * KW + kw];
+        }
+    }
+    dst[i] = from_f32<T>(v);
+}
+
+extern "C" int y5m_pack_weights(const float* src, int Cout, int Cin, int KH, int KW, int mode, int kh0, int khs,
+                                int th, int kw0, int kws, int tw, void* dst, int rows_p, int Kp, int cstride,
+                                int dtype, void* stream) {
+    const int64_t n = (int64_t)rows_p * Kp;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
+                                         src, Cout, Cin, KH, KW, mode, kh0, khs, th, kw0, kws, tw, (T*)dst, rows_p, Kp, cstride);)
+    Y5M_CHECK_LAUNCH("pack_weights_kernel");
+    return Y5M_OK;
+}
+
+// packed weight gradient f32 [N][taps][Cc] -> reference layout [Cout][Cin][KH][KW] (mode as above)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ gp, int Cout, int Cin, int KH, int KW, int mode,
+                                    int ldg, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)Cout * Cin * KH * KW;
+    if (i >= n) return;
+    const int kw = (int)(i % KW);
+    int64_t t = i / KW;
+    const int kh = (int)(t % KH);
+    t /= KH;
+    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    int k;
+    if (mode == 2) {
+        const int a = kh >> 1, dy = kh & 1, b = kw >> 1, dx = kw & 1;
+        k = (a * 3 + b) * 16 + (dy * 2 + dx) * 3 + ci;
+    } else {
+        k = (kh * KW + kw) * Cin + ci;
+    }
+    dst[i] = gp[(size_t)co * ldg + k];
+}
+
+extern "C" int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
+                                void* stream) {
+    const int64_t n = (int64_t)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), gp, Cout, Cin, KH,
+                       KW, mode, ldg, dst);
+    Y5M_CHECK_LAUNCH("unpack_wgrad_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// input: NCHW f32 image (B,3,H,W) -> space-to-depth NHWC (B,H/2,W/2,16): ch = (dy*2+dx)*3 + c
+// =================================================================================================
+template <typename T>
+__global__ void s2d_input_kernel(const float* __restrict__ img, int B, int H, int W, T* __restrict__ out) {
+    const int W2 = W >> 1, H2 = H >> 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per output pixel
+    if (i >= (int64_t)B * H2 * W2) return;
+    const int x = (int)(i % W2);
+    int64_t t = i / W2;
+    const int y = (int)(t % H2);
+    const int b = (int)(t / H2);
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const float2 q = *reinterpret_cast<const float2*>(img + (((size_t)b * 3 + c) * H + (2 * y + dy)) * W + 2 * x);
+            v[(dy * 2 + 0) * 3 + c] = q.x;
+            v[(dy * 2 + 1) * 3 + c] = q.y;
+        }
+    v[12] = v[13] = v[14] = v[15] = 0.0f;
+    store8<T>(out + i * 16, v);
+    store8<T>(out + i * 16 + 8, v + 8);
+}
+
+extern "C" int y5m_s2d_input(const float* img, int B, int H, int W, void* out, int dtype, void* stream) {
+    Y5M_REQUIRE((H % 2) == 0 && (W % 2) == 0, "H,W must be even");
+    const int64_t n = (int64_t)B * (H / 2) * (W / 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(s2d_input_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), img,
+                                         B, H, W, (T*)out);)
+    Y5M_CHECK_LAUNCH("s2d_input_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// BatchNorm (training): finalise statistics from the conv epilogue partials
+// =================================================================================================
+// stats [tiles_m][2][Np] (sum, sumsq) -> mean, biased var; scale = g*invstd, shift = b - mean*scale;
+// running stats: momentum, UNBIASED variance (reference model.py:17, nn.BatchNorm2d semantics)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int tiles_m, int Np, int C,
+                                                         double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, float momentum, float eps,
+                                                         float* __restrict__ scale, float* __restrict__ shift,
+                                                         float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                         int update_running) {
+    __shared__ double s1[16][17], s2[16][17];
+    const int cs = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cs;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int t = rs; t < tiles_m; t += 16) {
+            a += (double)stats[((size_t)t * 2 + 0) * Np + c];
+            b += (double)stats[((size_t)t * 2 + 1) * Np + c];
+        }
+    }
+    s1[rs][cs] = a; s2[rs][cs] = b;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) { a += s1[r][cs]; b += s2[r][cs]; }
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = invstd;
+        if (update_running) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+extern "C" int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, int64_t count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* mean_out, float* invstd_out, int update_running,
+                               void* stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, y5m_stream(stream), stats,
+                       tiles_m, Np, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                       mean_out, invstd_out, update_running);
+    Y5M_CHECK_LAUNCH("bn_finalize_kernel");
+    return Y5M_OK;
+}
+
+// eval-mode fold: scale = g/sqrt(rv+eps), shift = b - rm*scale
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                               int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+extern "C" int y5m_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           float eps, int C, float* scale, float* shift, void* stream) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, y5m_stream(stream), gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    Y5M_CHECK_LAUNCH("bn_fold_kernel");
+    return Y5M_OK;
+}
+
+// z = act(y*scale + shift) (+ res) ; one thread = 8 channels of one pixel
+template <typename T>
+__global__ void bn_act_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                              const float* __restrict__ shift, const T* __restrict__ res, int ldres, T* __restrict__ out,
+                              int ldout, int64_t M, int C8, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C8) return;
+    const int64_t m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    float v[8], sc[8], sh[8];
+    load8<T>(y + m * ldy + c, v);
+    load8<float>(scale + c, sc);
+    load8<float>(shift + c, sh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = v[k] * sc[k] + sh[k];
+        if (act == Y5M_ACT_SILU) v[k] = silu_f(v[k]);
+    }
+    if (res) {
+        float r[8];
+        load8<T>(res + m * ldres + c, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+    store8<T>(out + m * ldout + c, v);
+}
+
+extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
+                          void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    const int64_t n = M * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
+                                         (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, C / 8, act);)
+    Y5M_CHECK_LAUNCH("bn_act_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// BatchNorm + SiLU backward
+//   t = y*scale + shift ; z = silu(t) ; dt = dz * silu'(t) ; xhat = (y - mean)*invstd
+//   dbeta = sum dt ; dgamma = sum dt*xhat ; dy = gamma*invstd*(dt - dbeta/M - xhat*dgamma/M)
+// =================================================================================================
+__device__ __forceinline__ float silu_grad(float t) {
+    const float s = 1.0f / (1.0f + __expf(-t));
+    return s * (1.0f + t * (1.0f - s));
+}
+
+#define BNR_ROWS 256   // pixels per block in the reduce pass
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
+                                                           int ldy, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, int64_t M, int C, int act,
+                                                           float* __restrict__ part) {
+    // block = 256 threads: (C8 chunk lanes) x (row lanes); grid.x = row blocks, grid.y = channel groups of 64
+    __shared__ float sm[2][32][65];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;      // 8 chunks (64 ch) x 32 row lanes
+    const int c = blockIdx.y * 64 + cl * 8;
+    const int64_t m0 = (int64_t)blockIdx.x * BNR_ROWS;
+    float sb[8], sg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sb[k] = 0.f; sg[k] = 0.f; }
+    if (c < C) {
+        float sc[8], sh[8], mu[8], is[8];
+        load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(mean + c, mu); load8<float>(invstd + c, is);
+        for (int r = rl; r < BNR_ROWS; r += 32) {
+            const int64_t m = m0 + r;
+            if (m >= M) break;
+            float g[8], yv[8];
+            load8<T>(dz + m * lddz + c, g);
+            load8<T>(y + m * ldy + c, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = yv[k] * sc[k] + sh[k];
+                const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(t) : g[k];
+                sb[k] += dt;
+                sg[k] += dt * ((yv[k] - mu[k]) * is[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sm[0][rl][cl * 8 + k] = sb[k]; sm[1][rl][cl * 8 + k] = sg[k]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += sm[which][r][ch];
+        const int cc = blockIdx.y * 64 + ch;
+        if (cc < C) part[((size_t)blockIdx.x * 2 + which) * C + cc] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate) {
+    __shared__ double s1[16][17], s2[16][17];
+    const int cs = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cs;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int t = rs; t < nblk; t += 16) {
+            a += (double)part[((size_t)t * 2 + 0) * C + c];
+            b += (double)part[((size_t)t * 2 + 1) * C + c];
+        }
+    s1[rs][cs] = a; s2[rs][cs] = b;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) { a += s1[r][cs]; b += s2[r][cs]; }
+        if (accumulate) { dbeta[c] += (float)a; dgamma[c] += (float)b; }
+        else { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+    }
+}
+
+// dy = gamma*invstd*(dt - sb/M - xhat*sg/M)  where (sb, sg) are THIS step's sums (part finalised in ws)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ sbeta, const float* __restrict__ sgamma, float invM,
+                                    T* __restrict__ dy, int lddy, int64_t M, int C8, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C8) return;
+    const int64_t m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    float g[8], yv[8], sc[8], sh[8], mu[8], is[8], sb[8], sg[8];
+    load8<T>(dz + m * lddz + c, g);
+    load8<T>(y + m * ldy + c, yv);
+    load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(mean + c, mu); load8<float>(invstd + c, is);
+    load8<float>(sbeta + c, sb); load8<float>(sgamma + c, sg);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = yv[k] * sc[k] + sh[k];
+        const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(t) : g[k];
+        const float xh = (yv[k] - mu[k]) * is[k];
+        o[k] = sc[k] * (dt - sb[k] * invM - xh * sg[k] * invM);     // scale = gamma*invstd
+    }
+    store8<T>(dy + m * lddy + c, o);
+}
+
+extern "C" size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C) {
+    const size_t nblk = (size_t)((M + BNR_ROWS - 1) / BNR_ROWS);
+    return y5m_align(nblk * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + 256;
+}
+
+// Full BN+SiLU backward of one CBL: param grads (dgamma, dbeta: accumulate flag) and dy.
+extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
+                          float* dbeta, int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes,
+                          int dtype, void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    if (ws_bytes < y5m_bn_bwd_workspace_bytes(M, C)) { y5m_set_error("bn_bwd ws too small"); return Y5M_EWS; }
+    const int nblk = (int)((M + BNR_ROWS - 1) / BNR_ROWS);
+    float* part = reinterpret_cast<float*>(ws);
+    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + y5m_align((size_t)nblk * 2 * C * 4));
+    float* sbeta = sums, *sgamma = sums + C;
+    hipStream_t st = y5m_stream(stream);
+    const dim3 rgrid((unsigned)nblk, (unsigned)((C + 63) / 64));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, rgrid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y,
+                                         ldy, scale, shift, mean, invstd, M, C, act, part);)
+    Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, part, nblk, C, sgamma,
+                       sbeta, 0);
+    Y5M_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    // parameter gradients (d gamma, d beta) = the same sums
+    if (dgamma && dbeta) {
+        if (accumulate_param_grads) {
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, part, nblk, C,
+                               dgamma, dbeta, 1);
+            Y5M_CHECK_LAUNCH("bn_bwd_finalize_kernel(acc)");
+        } else {
+            if (hipMemcpyAsync(dbeta, sbeta, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(dgamma, sgamma, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                y5m_set_error("bn_bwd memcpy"); return Y5M_ELAUNCH;
+            }
+        }
+    }
+    const int64_t n = M * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)dz, lddz,
+                                         (const T*)y, ldy, scale, shift, mean, invstd, sbeta, sgamma, 1.0f / (float)M,
+                                         (T*)dy, lddy, M, C / 8, act);)
+    Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// gradient plumbing: dst (+)= src over (ptr, ld) views
+// =================================================================================================
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int64_t M, int C8,
+                           int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C8) return;
+    const int64_t m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    float v[8];
+    load8<T>(src + m * lds_ + c, v);
+    if (accumulate) {
+        float o[8];
+        load8<T>(dst + m * ldd + c, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += o[k];
+    }
+    store8<T>(dst + m * ldd + c, v);
+}
+extern "C" int y5m_add(const void* src, int ldsrc, void* dst, int lddst, int64_t M, int C, int accumulate, int dtype,
+                       void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    const int64_t n = M * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), (const T*)src,
+                                         ldsrc, (T*)dst, lddst, M, C / 8, accumulate);)
+    Y5M_CHECK_LAUNCH("add_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// nearest 2x upsample (reference model.py:225) and its backward (2x2 sum)
+// =================================================================================================
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ in, int ldin, int B, int H, int W, int C8, T* __restrict__ out,
+                                  int ldout) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * (2 * H) * (2 * W) * C8;
+    if (i >= n) return;
+    const int c = (int)(i % C8) * 8;
+    int64_t t = i / C8;
+    const int x = (int)(t % (2 * W)); t /= (2 * W);
+    const int y = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    const uint4* s = reinterpret_cast<const uint4*>(in + (((size_t)b * H + (y >> 1)) * W + (x >> 1)) * ldin + c);
+    uint4* d = reinterpret_cast<uint4*>(out + (((size_t)b * 2 * H + y) * 2 * W + x) * ldout + c);
+    d[0] = s[0];
+    if (sizeof(T) == 4) d[1] = s[1];
+}
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ g, int ldg, int B, int H, int W, int C8, T* __restrict__ gin,
+                                      int ldgin, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * H * W * C8;
+    if (i >= n) return;
+    const int c = (int)(i % C8) * 8;
+    int64_t t = i / C8;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float v[8];
+            load8<T>(g + (((size_t)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * ldg + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+    T* d = gin + (((size_t)b * H + y) * W + x) * ldgin + c;
+    if (accumulate) {
+        float o[8];
+        load8<T>(d, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += o[k];
+    }
+    store8<T>(d, acc);
+}
+extern "C" int y5m_upsample2x(const void* in, int ldin, int B, int H, int W, int C, void* out, int ldout, int dtype,
+                              void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    const int64_t n = (int64_t)B * 4 * H * W * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(upsample2x_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
+                                         (const T*)in, ldin, B, H, W, C / 8, (T*)out, ldout);)
+    Y5M_CHECK_LAUNCH("upsample2x_kernel");
+    return Y5M_OK;
+}
+extern "C" int y5m_upsample2x_bwd(const void* gout, int ldg, int B, int H, int W, int C, void* gin, int ldgin,
+                                  int accumulate, int dtype, void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    const int64_t n = (int64_t)B * H * W * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
+                                         (const T*)gout, ldg, B, H, W, C / 8, (T*)gin, ldgin, accumulate);)
+    Y5M_CHECK_LAUNCH("upsample2x_bwd_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// SPPF pooling (reference model.py:103-112): three cascaded MaxPool2d(5,1,2) == windows 5, 9, 13 of x
+// (padding is -inf, so max-of-max composes exactly). One launch writes the 3 concat slices.
+// =================================================================================================
+template <typename T>
+__global__ void sppf_pool_kernel(const T* __restrict__ x, int ld, int B, int H, int W, int C, T* __restrict__ o1,
+                                 T* __restrict__ o2, T* __restrict__ o3) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * H * W * C;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int y2 = yy + dy;
+        if (y2 < 0 || y2 >= H) continue;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int x2 = xx + dx;
+            if (x2 < 0 || x2 >= W) continue;
+            const float v = to_f32<T>(x[(((size_t)b * H + y2) * W + x2) * ld + c]);
+            const int r = max(abs(dy), abs(dx));
+            m13 = fmaxf(m13, v);
+            if (r <= 4) m9 = fmaxf(m9, v);
+            if (r <= 2) m5 = fmaxf(m5, v);
+        }
+    }
+    const size_t o = (((size_t)b * H + yy) * W + xx) * ld + c;
+    o1[o] = from_f32<T>(m5); o2[o] = from_f32<T>(m9); o3[o] = from_f32<T>(m13);
+}
+extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, int dtype,
+                             void* stream) {
+    const int64_t n = (int64_t)B * H * W * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(sppf_pool_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
+                                         (const T*)x, ld, B, H, W, C, (T*)o1, (T*)o2, (T*)o3);)
+    Y5M_CHECK_LAUNCH("sppf_pool_kernel");
+    return Y5M_OK;
+}
+
+// backward of ONE MaxPool2d(5,1,2): gin[i] (+)= sum over outputs o whose window argmax is i of g[o].
+// argmax = first maximum in (row, col) scan order, as ATen's max_pool2d_with_indices.
+template <typename T>
+__global__ void maxpool5_bwd_kernel(const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg, int B, int H,
+                                    int W, int C, T* __restrict__ gin, int ldgin, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * H * W * C;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    const T* zb = z + (size_t)b * H * W * ldz + c;
+    float acc = 0.f;
+    for (int oy = yy - 2; oy <= yy + 2; ++oy) {
+        if (oy < 0 || oy >= H) continue;
+        for (int ox = xx - 2; ox <= xx + 2; ++ox) {
+            if (ox < 0 || ox >= W) continue;
+            // argmax of window centred at (oy, ox)
+            float best = -INFINITY;
+            int by = -1, bx = -1;
+            for (int wy = oy - 2; wy <= oy + 2; ++wy) {
+                if (wy < 0 || wy >= H) continue;
+                for (int wx = ox - 2; wx <= ox + 2; ++wx) {
+                    if (wx < 0 || wx >= W) continue;
+                    const float v = to_f32<T>(zb[((size_t)wy * W + wx) * ldz]);
+                    if (v > best || by < 0) { best = v; by = wy; bx = wx; }
+                }
+            }
+            if (by == yy && bx == xx) acc += to_f32<T>(g[(((size_t)b * H + oy) * W + ox) * ldg + c]);
+        }
+    }
+    T* d = gin + (((size_t)b * H + yy) * W + xx) * ldgin + c;
+    if (accumulate) acc += to_f32<T>(*d);
+    *d = from_f32<T>(acc);
+}
+extern "C" int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
+                                int ldgin, int accumulate, int dtype, void* stream) {
+    const int64_t n = (int64_t)B * H * W * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
+                                         (const T*)z, ldz, (const T*)g, ldg, B, H, W, C, (T*)gin, ldgin, accumulate);)
+    Y5M_CHECK_LAUNCH("maxpool5_bwd_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// head gradient: d(loss)/d(logits) f32 (B,naxs,ny,nx,nch) -> dY [M=B*ny*nx][ldp] in compute dtype
+// (channel n = a*nch + c, columns >= naxs*nch zero) + bias gradient (column sums)
+// =================================================================================================
+template <typename T>
+__global__ void head_grad_pack_kernel(const float* __restrict__ dl, int B, int naxs, int ny, int nx, int nch,
+                                      T* __restrict__ dyp, int ldp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * ny * nx * ldp;
+    if (i >= n) return;
+    const int col = (int)(i % ldp);
+    const int64_t m = i / ldp;
+    float v = 0.f;
+    if (col < naxs * nch) {
+        const int a = col / nch, c = col - a * nch;
+        const int64_t pix = m % ((int64_t)ny * nx);
+        const int64_t b = m / ((int64_t)ny * nx);
+        v = dl[((b * naxs + a) * (int64_t)ny * nx + pix) * nch + c];
+    }
+    dyp[i] = from_f32<T>(v);
+}
+__global__ __launch_bounds__(128) void head_bias_grad_kernel(const float* __restrict__ dl, int B, int naxs, int64_t hw,
+                                                            int nch, float* __restrict__ dbias) {
+    // grid (naxs, splits); thread c walks rows (b, pix) of anchor a: coalesced along c
+    const int a = blockIdx.x, c = threadIdx.x;
+    if (c >= nch) return;
+    const int64_t rows = (int64_t)B * hw;
+    float acc = 0.f;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const int64_t b = r / hw, pix = r - b * hw;
+        acc += dl[((b * naxs + a) * hw + pix) * nch + c];
+    }
+    atomicAdd(&dbias[a * nch + c], acc);
+}
+extern "C" int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
+                                  float* dbias, int dtype, void* stream) {
+    Y5M_REQUIRE(nch <= 128 && ldp >= naxs * nch, "head dims");
+    const int64_t n = (int64_t)B * ny * nx * ldp;
+    hipStream_t st = y5m_stream(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, dlogits, B, naxs,
+                                         ny, nx, nch, (T*)dyp, ldp);)
+    Y5M_CHECK_LAUNCH("head_grad_pack_kernel");
+    if (dbias) {
+        if (hipMemsetAsync(dbias, 0, (size_t)naxs * nch * 4, st) != hipSuccess) { y5m_set_error("memset dbias"); return Y5M_ELAUNCH; }
+        hipLaunchKernelGGL(head_bias_grad_kernel, dim3((unsigned)naxs, 64), dim3(128), 0, st, dlogits, B, naxs,
+                           (int64_t)ny * nx, nch, dbias);
+        Y5M_CHECK_LAUNCH("head_bias_grad_kernel");
+    }
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// optimizer: global-norm clip (max_norm) + Adam with L2 weight decay (reference train.py:61,
+// utils/training_utils.py:116-122), one fused pass over the flat parameter buffer
+// =================================================================================================
+#define SQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 q = reinterpret_cast<const float4*>(g)[i];
+        acc += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    }
+    if (blockIdx.x == 0) for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += (double)part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]);   // total L2 norm
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, const float* __restrict__ gnorm, float max_norm, float lr, float b1, float b2,
+                            float eps, float wd, const int32_t* __restrict__ d_step) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // the step counter lives on the device so a captured hipGraph replays with the right bias correction
+    const float stepf = (float)d_step[0];
+    const float bc1 = 1.0f - powf(b1, stepf);
+    const float bc2_sqrt = sqrtf(1.0f - powf(b2, stepf));
+    float clip = 1.0f;
+    if (max_norm > 0.f) {                         // torch.nn.utils.clip_grad_norm_: coef = max/(norm+1e-6), clamped to 1
+        clip = max_norm / (gnorm[0] + 1e-6f);
+        clip = clip > 1.0f ? 1.0f : clip;
+    }
+    const float pw = p[i];
+    float gi = g[i] * clip;
+    gi = gi + wd * pw;                            // Adam(weight_decay=): L2 added to the gradient
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pw - (lr / bc1) * (mi / denom);
+}
+extern "C" size_t y5m_adam_workspace_bytes(void) { return (SQ_BLOCKS + 64) * sizeof(float); }
+extern "C" int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, void* stream) {
+    if (ws_bytes < y5m_adam_workspace_bytes()) { y5m_set_error("adam ws too small"); return Y5M_EWS; }
+    float* part = reinterpret_cast<float*>(ws);
+    hipStream_t st = y5m_stream(stream);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SQ_BLOCKS), dim3(256), 0, st, g, n, part);
+    Y5M_CHECK_LAUNCH("sumsq_kernel");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, part, SQ_BLOCKS, norm_out);
+    Y5M_CHECK_LAUNCH("sumsq_final_kernel");
+    return Y5M_OK;
+}
+extern "C" int y5m_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm, float max_norm,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_step,
+                             void* stream) {
+    Y5M_REQUIRE(d_step != nullptr, "d_step (device int32, >= 1) is required");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), p, g, m, v, n, gnorm, max_norm, lr,
+                       beta1, beta2, eps, weight_decay, d_step);
+    Y5M_CHECK_LAUNCH("adam_kernel");
+    return Y5M_OK;
+}

@@ -1,0 +1,502 @@
+"""Native execution plan for the YOLOv5m train / inference step.
+
+The topology (reference model.py:210-239) is static for a given (B, H, W, dtype, mode), so it is
+expanded ONCE into two flat launch lists -- forward and backward -- of pre-bound C-ABI calls over
+pre-allocated HBM buffers. Running a list enqueues HIP kernels on the current stream; nothing is
+allocated, nothing synchronises, so a whole step can be captured into one hipGraph and replayed.
+
+Memory plan (all resident in HBM, sized for 288 GB):
+  * activations are NHWC (pixel-major, channel-minor) in the compute dtype; every concat of the
+    reference (C3 :91, SPPF :112, PANet joins :226/:230) is a wider buffer whose producers write their
+    channel slice directly (ptr + offset, ld) -- torch.cat never materialises;
+  * training keeps, per CBL, the raw conv output (input of BN) for the backward pass;
+  * gradients mirror the activation buffers; one scratch holds dy of the layer being differentiated;
+  * weights: f32 masters (reference layout) -> packed K-contiguous copies in the compute dtype per
+    step (forward rows + data-gradient rows), weight gradients accumulate in packed f32.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .arch import BN_EPS, BN_MOMENTUM, blocks
+from ._lib import (ConvArgs, WgradArgs, EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD, EPI_DGRAD, ACT_NONE, ACT_SILU,
+                   F32, BF16)
+
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Act:
+    """A (ptr, ld) view of an NHWC activation: B x H x W pixels, C channels at channel offset `off`
+    inside a buffer whose pixel stride is `ld` elements."""
+
+    def __init__(self, buf, B, H, W, C, ld=None, off=0):
+        self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+        self.ld = ld if ld is not None else C
+        self.off = off
+        self.grad = None          # Act over the gradient buffer (training)
+        self.gw = False           # plan-time flag: gradient already written in this backward pass
+        self.children = []        # channel slices of a concat buffer
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.off * self.buf.element_size()
+
+    def slice(self, c0, C):
+        s = Act(self.buf, self.B, self.H, self.W, C, self.ld, self.off + c0)
+        if self.grad is not None:
+            s.grad = Act(self.grad.buf, self.B, self.H, self.W, C, self.grad.ld, self.grad.off + c0)
+        self.children.append(s)
+        return s
+
+    def as_nchw_f32(self):
+        """debug/test helper: dense (B,C,H,W) f32 copy"""
+        t = self.buf.view(-1)[: self.B * self.H * self.W * self.ld + 0] if False else None
+        flat = torch.as_strided(self.buf.view(-1), (self.B, self.H, self.W, self.C),
+                                (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), self.off)
+        return flat.permute(0, 3, 1, 2).float().contiguous()
+
+
+class _Layer:
+    """Per-CBL (or head conv) static data."""
+    pass
+
+
+class Engine:
+    def __init__(self, model, B, H, W, dtype=BF16, training=True, nt_max=0):
+        assert H % 32 == 0 and W % 32 == 0, "Width and Height aren't divisible by 32!"   # model.py:211
+        self.L = _lib.lib()
+        self.model = model
+        self.B, self.H, self.W = B, H, W
+        self.dtype = dtype
+        self.tdt = _TORCH_DT[dtype]
+        self.training = training
+        self.dev = model.flat_params.device
+        self.CH = 8 if dtype == BF16 else 4
+        self.BK = 64 if dtype == BF16 else 32
+        self.nc, self.naxs = model.head.nc, model.head.naxs
+        self.nch = 5 + self.nc
+        self.fwd, self.bwd = [], []
+        self._bwd_stack = []
+        self.layers = []
+        self._scratch_elems = 0
+        self._stats_floats = 0
+        self._bnws_bytes = 0
+        self._build()
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _new_act(self, B, H, W, C, need_grad=True):
+        buf = torch.zeros((B * H * W * C,), dtype=self.tdt, device=self.dev)
+        a = Act(buf, B, H, W, C)
+        if self.training and need_grad:
+            a.grad = Act(torch.zeros_like(buf), B, H, W, C)
+        return a
+
+    def _call(self, lst, fn, *args):
+        lst.append((fn, args))
+
+    # ------------------------------------------------------------------ conv descriptors
+    def _conv_args(self, x, w, out_ptr, Ho, Wo, k, s, p, N, ldout, epi, Kp, cin=None, **kw):
+        a = ConvArgs()
+        cin = cin if cin is not None else x.C
+        a.inp, a.w, a.out = x.ptr, w.data_ptr(), out_ptr
+        a.B, a.Hin, a.Win, a.ldin = x.B, x.H, x.W, x.ld
+        a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, s, s
+        a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -p, 1, -p, 1
+        a.Cin, a.K, a.Kp, a.N, a.M = cin, k * k * cin, Kp, N, x.B * Ho * Wo
+        a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = Ho, Wo, ldout, 1, 1, 0, 0
+        a.epi, a.act, a.accumulate = epi, ACT_NONE, 0
+        a.Np = _rup(N, self.L.y5m_conv_tile_n(N))
+        for key, v in kw.items():
+            setattr(a, key, v)
+        return a
+
+    def _run_conv(self, lst, a):
+        L, dt = self.L, self.dtype
+
+        def fn(a=a):
+            _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
+        lst.append((fn, ()))
+
+    # ------------------------------------------------------------------ building blocks
+    def _cbl(self, name, x, cout, k, s, p, dest=None, res=None, stem=False):
+        """reference model.py:12-28 (+ Bottleneck residual :50 when res is given)."""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        P = self.model.pslices[name]          # dict of flat-buffer views: w, g, b, rm, rv (+ grads)
+        lay = _Layer()
+        lay.name, lay.x, lay.res, lay.stem = name, x, res, stem
+        lay.cin_real = 3 if stem else x.C
+        lay.cout, lay.k, lay.s, lay.p = cout, k, s, p
+        kk, ss, pp = (3, 1, 1) if stem else (k, s, p)     # stem runs as 3x3/s1 on the s2d input
+        Ho = (x.H + 2 * pp - kk) // ss + 1
+        Wo = (x.W + 2 * pp - kk) // ss + 1
+        lay.Ho, lay.Wo = Ho, Wo
+        M = x.B * Ho * Wo
+        K = kk * kk * x.C
+        Kp = _rup(K, self.BK)
+        BN = L.y5m_conv_tile_n(cout)
+        Np = _rup(cout, BN)
+        lay.K, lay.Kp, lay.Np, lay.kk, lay.ss, lay.pp, lay.M = K, Kp, Np, kk, ss, pp, M
+        lay.wf = torch.zeros((Np, Kp), dtype=self.tdt, device=self.dev)
+        if dest is None:
+            dest = self._new_act(x.B, Ho, Wo, cout)
+        lay.z = dest
+        bn = torch.zeros((4, cout), dtype=torch.float32, device=self.dev)   # scale, shift, mean, invstd
+        lay.bn = bn
+        mode = 2 if stem else 0
+        # ---- per-step weight pack (masters may have changed)
+        self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, lay.cin_real, k, k, mode, 0, 1, kk, 0, 1,
+                   kk, _lib.ptr(lay.wf), Np, Kp, 0, dt)
+        if self.training:
+            lay.y = torch.zeros((M * cout,), dtype=self.tdt, device=self.dev)
+            tiles_m = (M + 127) // 128
+            self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np)
+            a = self._conv_args(x, lay.wf, lay.y.data_ptr(), Ho, Wo, kk, ss, pp, cout, cout, EPI_RAW_STATS, Kp)
+            lay.fwd_args = a
+            self._stat_users.append(a)
+            self._run_conv(self.fwd, a)
+
+            def finalize(lay=lay, P=P, tiles_m=tiles_m, Np=Np, M=M, bn=bn):
+                _lib.check(L.y5m_bn_finalize(_lib.ptr(self.stats), tiles_m, Np, lay.cout, M, _lib.ptr(P["g"]),
+                                             _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
+                                             BN_MOMENTUM, BN_EPS, bn[0].data_ptr(), bn[1].data_ptr(),
+                                             bn[2].data_ptr(), bn[3].data_ptr(), 1, st()), "y5m_bn_finalize")
+            self.fwd.append((finalize, ()))
+
+            def apply(lay=lay, bn=bn, dest=dest, res=res, M=M):
+                _lib.check(L.y5m_bn_act(_lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
+                                        res.ptr if res is not None else None, res.ld if res is not None else 0,
+                                        dest.ptr, dest.ld, M, lay.cout, ACT_SILU, dt, st()), "y5m_bn_act")
+            self.fwd.append((apply, ()))
+            self._cbl_backward(lay, P)
+        else:
+            def fold(lay=lay, P=P, bn=bn):
+                _lib.check(L.y5m_bn_fold(_lib.ptr(P["g"]), _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
+                                         BN_EPS, lay.cout, bn[0].data_ptr(), bn[1].data_ptr(), st()), "y5m_bn_fold")
+            self.pack.append((fold, ()))
+            a = self._conv_args(x, lay.wf, dest.ptr, Ho, Wo, kk, ss, pp, cout, dest.ld, EPI_AFFINE_ACT, Kp,
+                                act=ACT_SILU, scale=bn[0].data_ptr(), shift=bn[1].data_ptr(),
+                                res=res.ptr if res is not None else None, ldres=res.ld if res is not None else 0)
+            lay.fwd_args = a
+            self._run_conv(self.fwd, a)
+        self.layers.append(lay)
+        return dest
+
+    # backward of one CBL, pushed on a stack (executed in reverse order of the forward)
+    def _cbl_backward(self, lay, P):
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        M, cout = lay.M, lay.cout
+        self._scratch_elems = max(self._scratch_elems, M * cout)
+        self._bnws_bytes = max(self._bnws_bytes, L.y5m_bn_bwd_workspace_bytes(M, cout))
+        ntap = lay.kk * lay.kk
+        lay.gw_off = self._gw_floats
+        lay.ldgw = ntap * lay.x.C
+        self._gw_floats += lay.cout * lay.ldgw
+        # data-gradient weights
+        x = lay.x
+        need_dx = x.grad is not None
+        lay.wd = []
+        if need_dx:
+            if lay.ss == 1:
+                Kd = ntap * cout
+                wd = torch.zeros((_rup(x.C, L.y5m_conv_tile_n(x.C)), _rup(Kd, self.BK)), dtype=self.tdt, device=self.dev)
+                lay.wd.append((wd, 0, 0, lay.kk, 0, 1, lay.pp, 0, 1, lay.pp))   # (buf, py, px, th, kh0, khs, dh0, kw0, kws, dw0)
+                self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, x.C, lay.k, lay.k, 1, 0, 1, lay.kk,
+                           0, 1, lay.kk, _lib.ptr(wd), wd.shape[0], wd.shape[1], 0, dt)
+            else:
+                assert lay.ss == 2
+                for py in range(2):
+                    kh0 = (py + lay.pp) % 2
+                    th = len(range(kh0, lay.kk, 2))
+                    dh0 = (py + lay.pp - kh0) // 2
+                    for px in range(2):
+                        kw0 = (px + lay.pp) % 2
+                        tw = len(range(kw0, lay.kk, 2))
+                        dw0 = (px + lay.pp - kw0) // 2
+                        Kd = th * tw * cout
+                        wd = torch.zeros((_rup(x.C, L.y5m_conv_tile_n(x.C)), _rup(Kd, self.BK)), dtype=self.tdt,
+                                         device=self.dev)
+                        lay.wd.append((wd, py, px, (th, tw), kh0, 2, dh0, kw0, 2, dw0))
+                        self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, x.C, lay.k, lay.k, 1, kh0, 2,
+                                   th, kw0, 2, tw, _lib.ptr(wd), wd.shape[0], wd.shape[1], 0, dt)
+
+        def backward(lay=lay, P=P, need_dx=need_dx):
+            ops = []
+            z = lay.z
+            dz = z.grad
+            bn = lay.bn
+            # residual branch: d(res) (+)= dz   (Bottleneck add, model.py:50)
+            if lay.res is not None and lay.res.grad is not None:
+                acc = 1 if lay.res.gw else 0
+                lay.res.gw = True
+                rg = lay.res.grad
+                ops.append((lambda rg=rg, dz=dz, acc=acc: _lib.check(
+                    L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), ()))
+            # BN + SiLU backward -> dy (scratch), dgamma, dbeta
+            ops.append((lambda: _lib.check(
+                L.y5m_bn_bwd(dz.ptr, dz.ld, _lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
+                             bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]),
+                             _lib.ptr(P["gb"]), 0, _lib.ptr(self.scratch), lay.cout, _lib.ptr(self.bnws),
+                             self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ()))
+            # weight gradient (packed f32, atomics into the zeroed gw buffer)
+            wa = WgradArgs()
+            wa.dy, wa.x = self.scratch.data_ptr(), lay.x.ptr
+            wa.dwgt = self.gw.data_ptr() + 4 * lay.gw_off
+            wa.B, wa.Hin, wa.Win, wa.ldx = lay.x.B, lay.x.H, lay.x.W, lay.x.ld
+            wa.Hg, wa.Wg, wa.sy, wa.sx = lay.Ho, lay.Wo, lay.ss, lay.ss
+            wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = lay.kk, lay.kk, -lay.pp, 1, -lay.pp, 1
+            wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = lay.x.C, lay.cout, lay.M, lay.cout, lay.ldgw, 0
+            lay.wgrad_args = wa
+            ops.append((lambda wa=wa: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad"), ()))
+            # data gradient
+            if need_dx:
+                xg = lay.x.grad
+                acc = 1 if lay.x.gw else 0
+                lay.x.gw = True
+                for c in lay.x.children:
+                    c.gw = True
+                lay.dgrad_args = []
+                dyA = Act(self.scratch, lay.x.B, lay.Ho, lay.Wo, lay.cout)
+                for (wd, py, px, tht, kh0, khs, dh0, kw0, kws, dw0) in lay.wd:
+                    th, tw = (tht, tht) if isinstance(tht, int) else tht
+                    a = ConvArgs()
+                    a.inp, a.w, a.out = dyA.ptr, wd.data_ptr(), xg.ptr
+                    a.B, a.Hin, a.Win, a.ldin = dyA.B, dyA.H, dyA.W, dyA.ld
+                    if lay.ss == 1:
+                        a.Hg, a.Wg, a.osy, a.osx, a.ooy, a.oox = lay.x.H, lay.x.W, 1, 1, 0, 0
+                    else:
+                        a.Hg, a.Wg, a.osy, a.osx, a.ooy, a.oox = lay.x.H // 2, lay.x.W // 2, 2, 2, py, px
+                    a.sy, a.sx = 1, 1
+                    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = th, tw, dh0, -1, dw0, -1
+                    a.Cin, a.K, a.Kp = lay.cout, th * tw * lay.cout, wd.shape[1]
+                    a.N, a.M = lay.x.C, lay.x.B * a.Hg * a.Wg
+                    a.Hout, a.Wout, a.ldout = lay.x.H, lay.x.W, xg.ld
+                    a.epi, a.act, a.accumulate = EPI_DGRAD, ACT_NONE, acc
+                    a.Np = wd.shape[0]
+                    lay.dgrad_args.append(a)
+                    ops.append((lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), ()))
+            return ops
+        self._bwd_stack.append(backward)
+
+    def _c3(self, name, x, cout, width, depth, backbone, dest=None):
+        """reference model.py:54-92"""
+        c_ = int(width * x.C)
+        cat = self._new_act(x.B, x.H, x.W, 2 * c_)
+        s0, s1 = cat.slice(0, c_), cat.slice(c_, c_)
+        t = self._cbl(f"{name}.c1", x, c_, 1, 1, 0)
+        for d in range(depth):
+            last = d == depth - 1
+            if backbone:
+                u = self._cbl(f"{name}.seq.{d}.c1", t, c_, 1, 1, 0)
+                t = self._cbl(f"{name}.seq.{d}.c2", u, c_, 3, 1, 1, dest=s0 if last else None, res=t)
+            else:
+                u = self._cbl(f"{name}.seq.{d}.0", t, c_, 1, 1, 0)
+                t = self._cbl(f"{name}.seq.{d}.1", u, c_, 3, 1, 1, dest=s0 if last else None)
+        self._cbl(f"{name}.c_skipped", x, c_, 1, 1, 0, dest=s1)
+        return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0, dest=dest)
+
+    def _sppf(self, name, x, cout):
+        """reference model.py:96-112"""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        c_ = x.C // 2
+        cat = self._new_act(x.B, x.H, x.W, 4 * c_)
+        sl = [cat.slice(i * c_, c_) for i in range(4)]
+        self._cbl(f"{name}.c1", x, c_, 1, 1, 0, dest=sl[0])
+        self.fwd.append((lambda: _lib.check(L.y5m_sppf_pool(sl[0].ptr, cat.ld, x.B, x.H, x.W, c_, sl[1].ptr, sl[2].ptr,
+                                                           sl[3].ptr, dt, st()), "y5m_sppf_pool"), ()))
+        if self.training:
+            def backward():
+                ops = []
+                g = [s.grad for s in sl]
+                # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)   (cascade of model.py:108-110)
+                for lvl in (2, 1, 0):
+                    ops.append((lambda lvl=lvl: _lib.check(
+                        L.y5m_maxpool5_bwd(sl[lvl].ptr, cat.ld, g[lvl + 1].ptr, g[lvl + 1].ld, x.B, x.H, x.W, c_,
+                                           g[lvl].ptr, g[lvl].ld, 1, dt, st()), "y5m_maxpool5_bwd"), ()))
+                return ops
+            self._bwd_stack.append(backward)
+        return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0)
+
+    def _upsample_into(self, x, dst):
+        """reference model.py:225 (nearest x2), written straight into its concat slice"""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        self.fwd.append((lambda: _lib.check(L.y5m_upsample2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, dst.ptr, dst.ld, dt, st()),
+                                            "y5m_upsample2x"), ()))
+        if self.training:
+            def backward():
+                acc = 1 if x.gw else 0
+                x.gw = True
+                return [(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
+                                                                 x.grad.ptr, x.grad.ld, acc, dt, st()),
+                                            "y5m_upsample2x_bwd"), ())]
+            self._bwd_stack.append(backward)
+
+    def _head(self, i, x):
+        """reference model.py:162-175: 1x1 conv + bias, stored permuted as (B,naxs,ny,nx,5+nc) f32"""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        P = self.model.pslices[f"head.out_convs.{i}"]
+        N = self.naxs * self.nch
+        lay = _Layer()
+        lay.name, lay.x = f"head.out_convs.{i}", x
+        Kp = _rup(x.C, self.BK)
+        Np = _rup(N, L.y5m_conv_tile_n(N))
+        lay.wf = torch.zeros((Np, Kp), dtype=self.tdt, device=self.dev)
+        out = torch.zeros((x.B, self.naxs, x.H, x.W, self.nch), dtype=torch.float32, device=self.dev)
+        lay.out = out
+        self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), N, x.C, 1, 1, 0, 0, 1, 1, 0, 1, 1, _lib.ptr(lay.wf),
+                   Np, Kp, 0, dt)
+        a = self._conv_args(x, lay.wf, out.data_ptr(), x.H, x.W, 1, 1, 0, N, N, EPI_HEAD, Kp,
+                            scale=P["b"].data_ptr(), naxs=self.naxs, nch=self.nch)
+        lay.fwd_args = a
+        self._run_conv(self.fwd, a)
+        if self.training:
+            ldp = _rup(N, 16)                      # 255 -> 256: 16-byte rows for the MFMA operand loads
+            M = x.M
+            lay.gout = torch.zeros_like(out)       # d(loss)/d(logits), filled by the loss / autograd
+            self._scratch_elems = max(self._scratch_elems, M * ldp)
+            lay.gw_off = self._gw_floats
+            lay.ldgw = x.C
+            self._gw_floats += ldp * x.C
+            wd = torch.zeros((_rup(x.C, L.y5m_conv_tile_n(x.C)), _rup(ldp, self.BK)), dtype=self.tdt, device=self.dev)
+            self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), N, x.C, 1, 1, 1, 0, 1, 1, 0, 1, 1, _lib.ptr(wd),
+                       wd.shape[0], wd.shape[1], ldp, dt)
+
+            def backward(lay=lay, x=x, P=P, wd=wd, ldp=ldp, M=M, N=N):
+                ops = []
+                ops.append((lambda: _lib.check(
+                    L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(self.scratch),
+                                         ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack"), ()))
+                wa = WgradArgs()
+                wa.dy, wa.x, wa.dwgt = self.scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
+                wa.B, wa.Hin, wa.Win, wa.ldx = x.B, x.H, x.W, x.ld
+                wa.Hg, wa.Wg, wa.sy, wa.sx = x.H, x.W, 1, 1
+                wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
+                wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = x.C, ldp, M, ldp, x.C, 0
+                lay.wgrad_args = wa
+                ops.append((lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(head)"), ()))
+                acc = 1 if x.gw else 0
+                x.gw = True
+                a = ConvArgs()
+                a.inp, a.w, a.out = self.scratch.data_ptr(), wd.data_ptr(), x.grad.ptr
+                a.B, a.Hin, a.Win, a.ldin = x.B, x.H, x.W, ldp
+                a.Hg, a.Wg, a.sy, a.sx = x.H, x.W, 1, 1
+                a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = 1, 1, 0, -1, 0, -1
+                a.Cin, a.K, a.Kp, a.N, a.M = ldp, ldp, wd.shape[1], x.C, M
+                a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = x.H, x.W, x.grad.ld, 1, 1, 0, 0
+                a.epi, a.act, a.accumulate, a.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
+                lay.dgrad_args = [a]
+                ops.append((lambda: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(head dgrad)"), ()))
+                return ops
+            self._bwd_stack.append(backward)
+        self.heads.append(lay)
+        return out
+
+    # ------------------------------------------------------------------ whole-model plan
+    def _build(self):
+        L, dt = self.L, self.dtype
+        B, H, W = self.B, self.H, self.W
+        self.pack, self.heads, self._stat_users = [], [], []
+        self._gw_floats = 0
+        first_out = self.model.first_out
+        backbone, neck = blocks(first_out)
+        # input: NCHW f32 images -> space-to-depth NHWC (no gradient)
+        self.x_in = torch.zeros((B, 3, H, W), dtype=torch.float32, device=self.dev)
+        s2d = self._new_act(B, H // 2, W // 2, 16, need_grad=False)
+        self.fwd.append((lambda: _lib.check(L.y5m_s2d_input(_lib.ptr(self.x_in), B, H, W, s2d.ptr, dt, _lib.stream_ptr()),
+                                            "y5m_s2d_input"), ()))
+        f = first_out
+        # concat buffers of the PANet joins (model.py:226, :230); producers write their slices in place
+        cat1 = self._new_act(B, H // 16, W // 16, 16 * f)     # [up(neck0) | backbone6]
+        cat2 = self._new_act(B, H // 8, W // 8, 8 * f)        # [up(neck2) | backbone4]
+        cat3 = self._new_act(B, H // 16, W // 16, 8 * f)      # [neck4 | neck2]
+        cat4 = self._new_act(B, H // 32, W // 32, 16 * f)     # [neck6 | neck0]
+        c1a, c1b = cat1.slice(0, 8 * f), cat1.slice(8 * f, 8 * f)
+        c2a, c2b = cat2.slice(0, 4 * f), cat2.slice(4 * f, 4 * f)
+        c3a, c3b = cat3.slice(0, 4 * f), cat3.slice(4 * f, 4 * f)
+        c4a, c4b = cat4.slice(0, 8 * f), cat4.slice(8 * f, 8 * f)
+        dests = {4: c2b, 6: c1b}
+        x = s2d
+        for idx, (kind, a) in enumerate(backbone):
+            name = f"backbone.{idx}"
+            if kind == "cbl":
+                x = self._cbl(name, x, a["cout"], a["k"], a["s"], a["p"], stem=(idx == 0))
+            elif kind == "c3":
+                x = self._c3(name, x, a["cout"], a["width"], a["depth"], a["backbone"], dest=dests.get(idx))
+            else:
+                x = self._sppf(name, x, a["cout"])
+        n0 = self._cbl("neck.0", x, 8 * f, 1, 1, 0, dest=c4b)
+        self._upsample_into(n0, c1a)
+        n1 = self._c3("neck.1", cat1, 8 * f, 0.25, 2, False)
+        n2 = self._cbl("neck.2", n1, 4 * f, 1, 1, 0, dest=c3b)
+        self._upsample_into(n2, c2a)
+        n3 = self._c3("neck.3", cat2, 4 * f, 0.25, 2, False)
+        self._cbl("neck.4", n3, 4 * f, 3, 2, 1, dest=c3a)
+        n5 = self._c3("neck.5", cat3, 8 * f, 0.5, 2, False)
+        self._cbl("neck.6", n5, 8 * f, 3, 2, 1, dest=c4a)
+        n7 = self._c3("neck.7", cat4, 16 * f, 0.5, 2, False)
+        self.outs = [self._head(0, n3), self._head(1, n5), self._head(2, n7)]
+        # shared scratch
+        self.stats = torch.zeros((max(self._stats_floats, 1),), dtype=torch.float32, device=self.dev)
+        for a in self._stat_users:
+            a.stats = self.stats.data_ptr()
+        if self.training:
+            self.scratch = torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev)
+            self.bnws = torch.zeros((self._bnws_bytes,), dtype=torch.uint8, device=self.dev)
+            self.gw = torch.zeros((self._gw_floats,), dtype=torch.float32, device=self.dev)
+            # expand the backward stack in reverse order; plan-time gradient-written flags
+            self.bwd.append((lambda: self.gw.zero_(), ()))
+            for mk in reversed(self._bwd_stack):
+                self.bwd.extend(mk())
+            # packed f32 weight grads -> reference-layout flat gradient
+            for lay in self.layers:
+                P = self.model.pslices[lay.name]
+                mode = 2 if lay.stem else 0
+                self.bwd.append((lambda lay=lay, P=P, mode=mode: _lib.check(
+                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, lay.cout, lay.cin_real, lay.k, lay.k, mode,
+                                       lay.ldgw, _lib.ptr(P["gw"]), _lib.stream_ptr()), "y5m_unpack_wgrad"), ()))
+            for lay in self.heads:
+                P = self.model.pslices[lay.name]
+                N = self.naxs * self.nch
+                self.bwd.append((lambda lay=lay, P=P, N=N: _lib.check(
+                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, N, lay.x.C, 1, 1, 0, lay.ldgw,
+                                       _lib.ptr(P["gw"]), _lib.stream_ptr()), "y5m_unpack_wgrad(head)"), ()))
+
+    # ------------------------------------------------------------------ execution
+    @staticmethod
+    def _run(lst):
+        for fn, args in lst:
+            if args:
+                rc = fn(*args, _lib.stream_ptr())
+                if rc != 0:
+                    raise _lib.Y5MError(f"native call failed rc={rc}: {_lib.lib().y5m_last_error().decode()}")
+            else:
+                fn()
+
+    def forward(self, images=None):
+        """images (B,3,H,W) f32 on the device (or already copied into self.x_in). Returns the 3 logits
+        buffers (B,naxs,ny,nx,5+nc) f32 -- engine-owned, overwritten by the next forward."""
+        if images is not None:
+            self.x_in.copy_(images)
+        self._run(self.pack)
+        self._run(self.fwd)
+        return self.outs
+
+    def backward(self, grads=None):
+        """grads: 3 tensors d(loss)/d(logits) (or None if already written into head gout buffers).
+        Fills the model's flat gradient buffer (reference parameter layout)."""
+        assert self.training
+        if grads is not None:
+            for lay, g in zip(self.heads, grads):
+                lay.gout.copy_(g)
+        self._run(self.bwd)
+
+    def head_grad_buffers(self):
+        return [lay.gout for lay in self.heads]

@@ -1,0 +1,250 @@
+"""YOLOV5m -- same constructor / attributes / state_dict surface as the reference model.py:178-239,
+executed by the native gfx950 engine (yolov5m_amd/engine.py) instead of ATen.
+
+The sub-modules (CBL, Bottleneck, C3, SPPF, HEADS) exist to carry parameters under the reference's
+names (481 state_dict keys) with PyTorch's default initialisation; their tensors are
+re-pointed into ONE flat f32 parameter buffer (and one flat gradient buffer) the first time the model
+runs on the GPU, which is what the fused optimizer and the RCCL gradient all-reduce operate on.
+Only YOLOV5m.forward executes: it is a single autograd Function around the native forward/backward.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, config
+from .arch import cbl_list
+
+
+class CBL(nn.Module):
+    """reference model.py:12-28 (parameter container; BN eps=1e-3, momentum=0.03)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=False)
+        bn = nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
+        self.cbl = nn.Sequential(conv, bn, nn.SiLU(inplace=True))
+
+    def forward(self, x):
+        raise _lib.Y5MError("sub-modules are parameter containers; run the whole YOLOV5m (native engine)")
+
+
+class Bottleneck(nn.Module):
+    """reference model.py:32-50"""
+
+    def __init__(self, in_channels, out_channels, width_multiple=1):
+        super().__init__()
+        c_ = int(width_multiple * in_channels)
+        self.c1 = CBL(in_channels, c_, kernel_size=1, stride=1, padding=0)
+        self.c2 = CBL(c_, out_channels, kernel_size=3, stride=1, padding=1)
+
+
+class C3(nn.Module):
+    """reference model.py:54-92"""
+
+    def __init__(self, in_channels, out_channels, width_multiple=1, depth=1, backbone=True):
+        super().__init__()
+        c_ = int(width_multiple * in_channels)
+        self.c1 = CBL(in_channels, c_, kernel_size=1, stride=1, padding=0)
+        self.c_skipped = CBL(in_channels, c_, kernel_size=1, stride=1, padding=0)
+        if backbone:
+            self.seq = nn.Sequential(*[Bottleneck(c_, c_, width_multiple=1) for _ in range(depth)])
+        else:
+            self.seq = nn.Sequential(*[nn.Sequential(CBL(c_, c_, 1, 1, 0), CBL(c_, c_, 3, 1, 1)) for _ in range(depth)])
+        self.c_out = CBL(c_ * 2, out_channels, kernel_size=1, stride=1, padding=0)
+
+
+class SPPF(nn.Module):
+    """reference model.py:96-112"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        c_ = int(in_channels // 2)
+        self.c1 = CBL(in_channels, c_, 1, 1, 0)
+        self.pool = nn.MaxPool2d(kernel_size=5, stride=1, padding=2)
+        self.c_out = CBL(c_ * 4, out_channels, 1, 1, 0)
+
+
+class HEADS(nn.Module):
+    """reference model.py:143-175"""
+
+    def __init__(self, nc=80, anchors=(), ch=()):
+        super().__init__()
+        self.nc = nc
+        self.nl = len(anchors)
+        self.naxs = len(anchors[0])
+        self.stride = [8, 16, 32]
+        anchors_ = torch.tensor(anchors).float().view(self.nl, -1, 2) / \
+            torch.tensor(self.stride).repeat(6, 1).T.reshape(3, 3, 2)
+        self.register_buffer("anchors", anchors_)
+        self.out_convs = nn.ModuleList()
+        for in_channels in ch:
+            self.out_convs += [nn.Conv2d(in_channels=in_channels, out_channels=(5 + self.nc) * self.naxs, kernel_size=1)]
+
+
+class _ModelFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward = native forward plan, backward = native
+    backward plan; parameter gradients come back as views of the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        eng = model._engine_for(x)
+        outs = eng.forward(x)
+        ctx.model, ctx.eng = model, eng
+        if model.static_outputs:
+            return tuple(outs)
+        return tuple(o.clone() for o in outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        model, eng = ctx.model, ctx.eng
+        grads = []
+        for g, o in zip((g0, g1, g2), eng.outs):
+            grads.append(g.contiguous().float() if g is not None else torch.zeros_like(o))
+        eng.backward(grads)
+        return (None, None) + tuple(model._grad_views())
+
+
+class YOLOV5m(nn.Module):
+    """reference model.py:178-239"""
+
+    def __init__(self, first_out, nc=80, anchors=(), ch=(), inference=False):
+        super().__init__()
+        self.inference = inference
+        self.first_out = first_out
+        f = first_out
+        self.backbone = nn.ModuleList()
+        self.backbone += [
+            CBL(in_channels=3, out_channels=f, kernel_size=6, stride=2, padding=2),
+            CBL(in_channels=f, out_channels=f * 2, kernel_size=3, stride=2, padding=1),
+            C3(in_channels=f * 2, out_channels=f * 2, width_multiple=0.5, depth=2),
+            CBL(in_channels=f * 2, out_channels=f * 4, kernel_size=3, stride=2, padding=1),
+            C3(in_channels=f * 4, out_channels=f * 4, width_multiple=0.5, depth=4),
+            CBL(in_channels=f * 4, out_channels=f * 8, kernel_size=3, stride=2, padding=1),
+            C3(in_channels=f * 8, out_channels=f * 8, width_multiple=0.5, depth=6),
+            CBL(in_channels=f * 8, out_channels=f * 16, kernel_size=3, stride=2, padding=1),
+            C3(in_channels=f * 16, out_channels=f * 16, width_multiple=0.5, depth=2),
+            SPPF(in_channels=f * 16, out_channels=f * 16),
+        ]
+        self.neck = nn.ModuleList()
+        self.neck += [
+            CBL(in_channels=f * 16, out_channels=f * 8, kernel_size=1, stride=1, padding=0),
+            C3(in_channels=f * 16, out_channels=f * 8, width_multiple=0.25, depth=2, backbone=False),
+            CBL(in_channels=f * 8, out_channels=f * 4, kernel_size=1, stride=1, padding=0),
+            C3(in_channels=f * 8, out_channels=f * 4, width_multiple=0.25, depth=2, backbone=False),
+            CBL(in_channels=f * 4, out_channels=f * 4, kernel_size=3, stride=2, padding=1),
+            C3(in_channels=f * 8, out_channels=f * 8, width_multiple=0.5, depth=2, backbone=False),
+            CBL(in_channels=f * 8, out_channels=f * 8, kernel_size=3, stride=2, padding=1),
+            C3(in_channels=f * 16, out_channels=f * 16, width_multiple=0.5, depth=2, backbone=False),
+        ]
+        self.head = HEADS(nc=nc, anchors=anchors, ch=ch)
+        # native-engine state
+        self.compute_dtype = "bf16"        # "bf16" (throughput) | "f32" (parity: exact-f32 MFMA)
+        self.static_outputs = False        # True: forward returns the engine's own output buffers
+        self.flat_params = None
+        self.flat_grads = None
+        self.pslices = None
+        self._engines = {}
+        self._flat_device = None
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _named_units(self):
+        """(unit name, conv module, bn module or None) in state_dict order"""
+        mods = dict(self.named_modules())
+        units = [(c.name, mods[c.name + ".cbl.0"], mods[c.name + ".cbl.1"]) for c in cbl_list(self.first_out)]
+        for i in range(self.head.nl):
+            units.append((f"head.out_convs.{i}", mods[f"head.out_convs.{i}"], None))
+        return units
+
+    def flatten_parameters(self):
+        """Re-point every parameter into one flat f32 buffer (and gradients into another). Idempotent
+        per device. Running BN statistics are flattened too (one f32 buffer + one int64 counter buffer)."""
+        dev = next(self.parameters()).device
+        if self._flat_device == dev and self.flat_params is not None:
+            return
+        if dev.type != "cuda":
+            raise _lib.Y5MError("YOLOV5m runs on the MI355X only: call .to('cuda') first (no CPU fallback)")
+        params = list(self.parameters())
+        n = sum(p.numel() for p in params)
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._param_list, self._grad_list = [], []
+        off = 0
+        pmap = {}
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                flat[off:off + k].copy_(p.detach().reshape(-1).float())
+                p.data = flat[off:off + k].view(p.shape)
+                pmap[id(p)] = gflat[off:off + k].view(p.shape)
+                self._param_list.append(p)
+                self._grad_list.append(pmap[id(p)])
+                off += k
+        units = self._named_units()
+        nstat = sum(bn.num_features for _, _, bn in units if bn is not None)
+        sflat = torch.empty(2 * nstat, dtype=torch.float32, device=dev)
+        nbt = torch.zeros(sum(1 for _, _, bn in units if bn is not None), dtype=torch.int64, device=dev)
+        so, bi = 0, 0
+        self.pslices = {}
+        with torch.no_grad():
+            for name, conv, bn in units:
+                d = {"w": conv.weight.data, "gw": pmap[id(conv.weight)]}
+                if bn is not None:
+                    c = bn.num_features
+                    sflat[so:so + c].copy_(bn.running_mean)
+                    sflat[nstat + so:nstat + so + c].copy_(bn.running_var)
+                    nbt[bi] = bn.num_batches_tracked
+                    bn.running_mean = sflat[so:so + c]
+                    bn.running_var = sflat[nstat + so:nstat + so + c]
+                    bn.num_batches_tracked = nbt[bi]
+                    d.update(g=bn.weight.data, b=bn.bias.data, rm=bn.running_mean, rv=bn.running_var,
+                             gg=pmap[id(bn.weight)], gb=pmap[id(bn.bias)])
+                    so += c
+                    bi += 1
+                else:
+                    d.update(b=conv.bias.data, gb=pmap[id(conv.bias)])
+                self.pslices[name] = d
+        self.flat_params, self.flat_grads, self._flat_stats, self._nbt = flat, gflat, sflat, nbt
+        self._flat_device = dev
+        self._engines = {}
+
+    def _grad_views(self):
+        return self._grad_list
+
+    def _check_flat(self):
+        """parameters must still alias the flat buffer (a .to()/.half() after flattening breaks it)"""
+        p0 = self._param_list[0]
+        if p0.data_ptr() != self.flat_params.data_ptr():
+            self.flat_params = None
+            self.flatten_parameters()
+
+    def _engine_for(self, x):
+        from .engine import Engine
+        self.flatten_parameters()
+        self._check_flat()
+        B, _, H, W = x.shape
+        dt = _lib.BF16 if self.compute_dtype == "bf16" else _lib.F32
+        key = (B, H, W, dt, self.training)
+        eng = self._engines.get(key)
+        if eng is None:
+            if len(self._engines) >= 4:        # bound resident plans (multi-scale training varies H,W)
+                self._engines.pop(next(iter(self._engines)))
+            eng = self._engines[key] = Engine(self, B, H, W, dtype=dt, training=self.training)
+        return eng
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x):
+        assert x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0, "Width and Height aren't divisible by 32!"
+        _lib.require_cuda(x)
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        self.flatten_parameters()
+        if self.training:
+            self._nbt += 1                      # BatchNorm2d.num_batches_tracked
+        if torch.is_grad_enabled() and self.training:
+            outs = _ModelFn.apply(self, x, *self._param_list)
+        else:
+            eng = self._engine_for(x)
+            outs = eng.forward(x)
+            if not self.static_outputs:
+                outs = [o.clone() for o in outs]
+        return list(outs)

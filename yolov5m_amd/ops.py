@@ -1,0 +1,167 @@
+"""Functional single-op wrappers over the C ABI (NCHW f32 in / out, layout conversion by torch).
+
+These are the op-level surface the parity tests drive (the model itself goes through engine.py with
+resident NHWC buffers and never converts layouts). dtype: "f32" or "bf16".
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, WgradArgs, EPI_DGRAD, EPI_AFFINE_ACT, EPI_RAW_STATS, ACT_NONE, ACT_SILU, F32, BF16
+
+_DT = {"f32": (F32, torch.float32, 4, 32), "bf16": (BF16, torch.bfloat16, 8, 64)}
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def to_nhwc(x, tdt, cpad=None):
+    B, C, H, W = x.shape
+    Cp = cpad or C
+    out = torch.zeros((B, H, W, Cp), dtype=tdt, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(tdt)
+    return out
+
+
+def from_nhwc(x, C=None):
+    return x[..., : (C or x.shape[-1])].permute(0, 3, 1, 2).float().contiguous()
+
+
+def pack_fwd(w, dtype):
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    Cout, Cin, k, _ = w.shape
+    Kp = _rup(k * k * Cin, BK)
+    Np = _rup(Cout, L.y5m_conv_tile_n(Cout))
+    wf = torch.zeros((Np, Kp), dtype=tdt, device=w.device)
+    _lib.check(L.y5m_pack_weights(_lib.ptr(w.contiguous().float()), Cout, Cin, k, k, 0, 0, 1, k, 0, 1, k, _lib.ptr(wf),
+                                  Np, Kp, 0, dt, _lib.stream_ptr()), "y5m_pack_weights")
+    return wf, Kp, Np
+
+
+def conv_forward(x, w, stride, pad, dtype="f32", scale=None, shift=None, act=False, res=None):
+    """x (B,Cin,H,W), w (Cout,Cin,k,k) -> (B,Cout,Ho,Wo). Optional fused affine + SiLU + residual."""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    _lib.require_cuda(x, w)
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    assert Cin % CH == 0 and Cout % 4 == 0
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xn = to_nhwc(x, tdt)
+    wf, Kp, Np = pack_fwd(w, dtype)
+    out = torch.zeros((B, Ho, Wo, Cout), dtype=tdt, device=x.device)
+    a = ConvArgs()
+    a.inp, a.w, a.out = xn.data_ptr(), wf.data_ptr(), out.data_ptr()
+    a.B, a.Hin, a.Win, a.ldin = B, H, W, Cin
+    a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
+    a.Cin, a.K, a.Kp, a.N, a.M = Cin, k * k * Cin, Kp, Cout, B * Ho * Wo
+    a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = Ho, Wo, Cout, 1, 1, 0, 0
+    a.Np = Np
+    keep = []
+    if scale is not None:
+        sc, sh = scale.float().contiguous(), shift.float().contiguous()
+        keep += [sc, sh]
+        a.epi, a.act = EPI_AFFINE_ACT, (ACT_SILU if act else ACT_NONE)
+        a.scale, a.shift = sc.data_ptr(), sh.data_ptr()
+        if res is not None:
+            rn = to_nhwc(res, tdt)
+            keep.append(rn)
+            a.res, a.ldres = rn.data_ptr(), Cout
+    else:
+        a.epi = EPI_DGRAD
+    _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
+    torch.cuda.synchronize()
+    return from_nhwc(out)
+
+
+def conv_forward_stats(x, w, stride, pad, dtype="f32"):
+    """raw conv output + the per-channel (sum, sumsq) the training epilogue emits"""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xn = to_nhwc(x, tdt)
+    wf, Kp, Np = pack_fwd(w, dtype)
+    out = torch.zeros((B, Ho, Wo, Cout), dtype=tdt, device=x.device)
+    M = B * Ho * Wo
+    tiles_m = (M + 127) // 128
+    stats = torch.zeros((tiles_m, 2, Np), dtype=torch.float32, device=x.device)
+    a = ConvArgs()
+    a.inp, a.w, a.out = xn.data_ptr(), wf.data_ptr(), out.data_ptr()
+    a.B, a.Hin, a.Win, a.ldin = B, H, W, Cin
+    a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
+    a.Cin, a.K, a.Kp, a.N, a.M = Cin, k * k * Cin, Kp, Cout, M
+    a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = Ho, Wo, Cout, 1, 1, 0, 0
+    a.Np, a.epi, a.stats = Np, EPI_RAW_STATS, stats.data_ptr()
+    _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
+    torch.cuda.synchronize()
+    s = stats.sum(0)
+    return from_nhwc(out), s[0, :Cout], s[1, :Cout]
+
+
+def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32"):
+    """dy (B,Cout,Ho,Wo), w (Cout,Cin,k,k) -> dx (B,Cin,H,W): autograd of conv2d wrt its input."""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    B, Cout, Ho, Wo = dy.shape
+    _, Cin, k, _ = w.shape
+    H, W = in_hw
+    dyn = to_nhwc(dy, tdt)
+    dx = torch.zeros((B, H, W, Cin), dtype=tdt, device=dy.device)
+    wsrc = w.contiguous().float()
+    classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(2) for px in range(2)]
+    for (py, px) in classes:
+        if stride == 1:
+            kh0, khs, th, dh0 = 0, 1, k, pad
+            kw0, kws, tw, dw0 = 0, 1, k, pad
+        else:
+            kh0 = (py + pad) % 2; th = len(range(kh0, k, 2)); dh0 = (py + pad - kh0) // 2; khs = 2
+            kw0 = (px + pad) % 2; tw = len(range(kw0, k, 2)); dw0 = (px + pad - kw0) // 2; kws = 2
+        Kd = th * tw * Cout
+        rows = _rup(Cin, L.y5m_conv_tile_n(Cin))
+        wd = torch.zeros((rows, _rup(Kd, BK)), dtype=tdt, device=dy.device)
+        _lib.check(L.y5m_pack_weights(_lib.ptr(wsrc), Cout, Cin, k, k, 1, kh0, khs, th, kw0, kws, tw, _lib.ptr(wd),
+                                      wd.shape[0], wd.shape[1], 0, dt, _lib.stream_ptr()), "y5m_pack_weights")
+        a = ConvArgs()
+        a.inp, a.w, a.out = dyn.data_ptr(), wd.data_ptr(), dx.data_ptr()
+        a.B, a.Hin, a.Win, a.ldin = B, Ho, Wo, Cout
+        if stride == 1:
+            a.Hg, a.Wg, a.osy, a.osx, a.ooy, a.oox = H, W, 1, 1, 0, 0
+        else:
+            a.Hg, a.Wg, a.osy, a.osx, a.ooy, a.oox = H // 2, W // 2, 2, 2, py, px
+        a.sy, a.sx = 1, 1
+        a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = th, tw, dh0, -1, dw0, -1
+        a.Cin, a.K, a.Kp, a.N, a.M = Cout, Kd, wd.shape[1], Cin, B * a.Hg * a.Wg
+        a.Hout, a.Wout, a.ldout = H, W, Cin
+        a.epi, a.Np = EPI_DGRAD, wd.shape[0]
+        _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv(dgrad)")
+        torch.cuda.synchronize()
+    return from_nhwc(dx)
+
+
+def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0):
+    """dy (B,Cout,Ho,Wo), x (B,Cin,H,W) -> dw (Cout,Cin,k,k): autograd of conv2d wrt its weight."""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    B, Cout, Ho, Wo = dy.shape
+    _, Cin, H, W = x.shape
+    dyn, xn = to_nhwc(dy, tdt), to_nhwc(x, tdt)
+    gp = torch.zeros((Cout, k * k * Cin), dtype=torch.float32, device=dy.device)
+    a = WgradArgs()
+    a.dy, a.x, a.dwgt = dyn.data_ptr(), xn.data_ptr(), gp.data_ptr()
+    a.B, a.Hin, a.Win, a.ldx = B, H, W, Cin
+    a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
+    a.C, a.N, a.M, a.lddy, a.lddw, a.ksplit = Cin, Cout, B * Ho * Wo, Cout, k * k * Cin, ksplit
+    _lib.check(L.y5m_wgrad(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_wgrad")
+    out = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=dy.device)
+    _lib.check(L.y5m_unpack_wgrad(_lib.ptr(gp), Cout, Cin, k, k, 0, k * k * Cin, _lib.ptr(out), _lib.stream_ptr()),
+               "y5m_unpack_wgrad")
+    torch.cuda.synchronize()
+    return out

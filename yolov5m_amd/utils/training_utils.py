@@ -1,0 +1,161 @@
+"""Train-step mechanics -- the callers of the hot path in the reference's utils/training_utils.py.
+
+Two entry points:
+  * train_loop(...)       : same signature and control flow as the reference (:81-132): autograd through
+                            the native model + native loss, torch.optim step. AMP's GradScaler is a no-op
+                            here: the native path computes bf16 activations with f32 accumulation and f32
+                            gradients of the loss, so no loss scaling is needed.
+  * NativeTrainStep       : the whole step (forward, build-targets + loss, backward, global-norm clip,
+                            Adam with L2 decay) as one native launch list over flat buffers, optionally
+                            captured into a hipGraph. This is what bench.py measures and what the
+                            data-parallel driver (yolov5m_amd/parallel.py) wraps.
+"""
+import ctypes
+import math
+import random
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, config
+
+
+def multi_scale(img, target_shape, max_stride):
+    """reference utils/training_utils.py:11-28 (random size in [0.5x, 1x+stride) rounded to the stride,
+    bilinear). Pure resampling of the input batch on whatever device it lives."""
+    sz = random.randrange(int(target_shape * 0.5), int(target_shape + max_stride)) // max_stride * max_stride
+    sf = sz / max(img.shape[2:])
+    h, w = img.shape[2:]
+    ns = [math.ceil(i * sf / max_stride) * max_stride for i in [h, w]]
+    return nn.functional.interpolate(img, size=ns, mode="bilinear", align_corners=False)
+
+
+def train_loop(model, loader, optim, loss_fn, scaler=None, epoch=0, num_epochs=1, multi_scale_training=True):
+    """reference utils/training_utils.py:81-132 (tqdm/printing dropped; returns the mean loss)."""
+    nbs = 64                                                   # :87 nominal batch size
+    batch_size = len(next(iter(loader))[0])                    # :88
+    accumulate = max(round(nbs / batch_size), 1)               # :89
+    last_opt_step = -1
+    loss_epoch = 0.0
+    nb = len(loader)
+    optim.zero_grad()
+    for idx, (images, bboxes) in enumerate(loader):
+        images = images.float() / 255                          # :98
+        if multi_scale_training:
+            images = multi_scale(images, target_shape=640, max_stride=32)
+        images = images.to(config.DEVICE, non_blocking=True)   # :102
+        out = model(images)                                    # :107
+        loss = loss_fn(out, bboxes, pred_size=images.shape[2:4], batch_idx=idx, epoch=epoch)
+        loss_epoch += float(loss.detach())
+        loss.backward()                                        # :114
+        if idx - last_opt_step >= accumulate or (idx == nb - 1):
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)   # :118
+            optim.step()
+            optim.zero_grad(set_to_none=True)
+            last_opt_step = idx
+    return loss_epoch / max(nb, 1)
+
+
+class NativeTrainStep:
+    """Fused native train step on flat buffers.
+
+    step(images, targets): images (B,3,H,W) f32 in [0,1] on the device, targets (nt,6)
+    [img, cls, x, y, w, h] (reference collate_fn_ultra format, dataset.py:204-209).
+    Optimizer = Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay) with L2-in-gradient (train.py:61)
+    after clip_grad_norm_(max_norm) (training_utils.py:118).
+    grad_hook: optional callable(flat_grads) run between backward and the optimizer (the data-parallel
+    all-reduce plugs in here)."""
+
+    def __init__(self, model, loss_fn, lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY, max_norm=10.0,
+                 betas=(0.9, 0.999), eps=1e-8, nt_max=1024, use_graph=False, grad_hook=None):
+        self.model, self.loss_fn = model, loss_fn
+        self.lr, self.wd, self.max_norm, self.betas, self.eps = lr, weight_decay, max_norm, betas, eps
+        self.nt_max = nt_max
+        self.use_graph = use_graph
+        self.grad_hook = grad_hook
+        model.train()
+        model.flatten_parameters()
+        dev = model.flat_params.device
+        n = model.flat_params.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.d_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        self.aws_bytes = L.y5m_adam_workspace_bytes()
+        self.aws = torch.zeros(self.aws_bytes, dtype=torch.uint8, device=dev)
+        self.targets = torch.zeros((nt_max, 6), dtype=torch.float32, device=dev)
+        self.d_nt = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss_out = None
+        self._graph = None
+        self._key = None
+        self._ws = None
+
+    # the launch list of one step (everything after the inputs are in place)
+    def _enqueue(self, eng):
+        from ..ultralytics_loss import _Workspace
+        L = _lib.lib()
+        model, lf = self.model, self.loss_fn
+        st = _lib.stream_ptr()
+        outs = eng.forward(None)
+        B = eng.B
+        shapes = [(o.shape[2], o.shape[3]) for o in outs]
+        if self._ws is None or self._ws.key != (B, eng.naxs, tuple(shapes), self.nt_max):
+            self._ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
+        ws = self._ws
+        _lib.check(L.y5m_build_targets(_lib.ptr(self.targets), 0, _lib.ptr(self.d_nt), self.nt_max,
+                                       _lib.ptr(lf.anchors), eng.naxs, ws.ny, ws.nx, float(lf.anchor_t), ws.tg,
+                                       _lib.ptr(ws.bt_ws), ws.bt_ws_bytes, st), "y5m_build_targets")
+        grads = eng.head_grad_buffers()
+        _lib.check(L.y5m_compute_loss(_lib.ptr_array(outs), _lib.ptr_array(grads), B, eng.naxs, ws.ny, ws.nx, lf.nc,
+                                      ws.tg, self.nt_max, _lib.float_array(lf.balance), float(lf.lambda_box),
+                                      float(lf.lambda_obj), float(lf.lambda_class), _lib.ptr(ws.loss_out),
+                                      _lib.ptr(ws.loss_ws), ws.loss_ws_bytes, st), "y5m_compute_loss")
+        self.loss_out = ws.loss_out
+        eng.backward(None)
+        if self.grad_hook is not None:
+            self.grad_hook(model.flat_grads)
+        self._optimizer(st)
+
+    def _optimizer(self, st):
+        L = _lib.lib()
+        model = self.model
+        n = model.flat_params.numel()
+        self.d_step += 1
+        _lib.check(L.y5m_grad_norm(_lib.ptr(model.flat_grads), n, _lib.ptr(self.gnorm), _lib.ptr(self.aws),
+                                   self.aws_bytes, st), "y5m_grad_norm")
+        _lib.check(L.y5m_adam_step(_lib.ptr(model.flat_params), _lib.ptr(model.flat_grads), _lib.ptr(self.m),
+                                   _lib.ptr(self.v), n, _lib.ptr(self.gnorm), float(self.max_norm), float(self.lr),
+                                   float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+                                   _lib.ptr(self.d_step), st), "y5m_adam_step")
+
+    def load_inputs(self, images, targets):
+        eng = self.model._engine_for(images)
+        eng.x_in.copy_(images, non_blocking=True)
+        nt = int(targets.shape[0])
+        if nt > self.nt_max:
+            raise _lib.Y5MError(f"nt={nt} exceeds nt_max={self.nt_max}")
+        if nt:
+            self.targets[:nt].copy_(targets.reshape(-1, 6).float(), non_blocking=True)
+        self.d_nt.fill_(nt)
+        return eng
+
+    def step(self, images, targets):
+        """Returns the device tensor [loss*bs, lbox, lobj, lcls] of THIS step (no host sync)."""
+        eng = self.load_inputs(images, targets)
+        self.model._nbt += 1
+        key = (id(eng),)
+        if not self.use_graph:
+            self._enqueue(eng)
+            return self.loss_out
+        if self._graph is None or self._key != key:
+            # warm-up once eagerly (module loading, attribute setting), then capture
+            self._enqueue(eng)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(eng)
+            self._graph, self._key = g, key
+            return self.loss_out
+        self._graph.replay()
+        return self.loss_out
