@@ -1,0 +1,44 @@
+"""CPU: the module mirror exposes the reference's state_dict / attribute surface and
+the execution plan is consistent (no GPU needed: nothing is launched)."""
+import pytest
+import torch
+
+from yolov5m_amd import config
+from yolov5m_amd.arch import state_dict_spec, cbl_list
+from yolov5m_amd.model import YOLOV5m
+from yolov5m_amd.utils.synth import synth_state_dict
+
+
+def _m():
+    return YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+
+
+def test_state_dict_surface():
+    m = _m()
+    sd = m.state_dict()
+    spec = state_dict_spec()
+    assert len(sd) == 481
+    assert [k for k, _, _ in spec] == list(sd.keys())
+    assert all(tuple(sd[k].shape) == tuple(s) for k, s, _ in spec)
+    assert sum(p.numel() for p in m.parameters()) == 21190557
+    assert len(cbl_list()) == 79
+    m.load_state_dict(synth_state_dict(), strict=True)
+
+
+def test_head_attributes():
+    m = _m()
+    assert (m.head.nc, m.head.nl, m.head.naxs, m.head.stride) == (80, 3, 3, [8, 16, 32])
+    a = m.head.anchors
+    assert a.shape == (3, 3, 2)
+    assert torch.allclose(a[0], torch.tensor([[1.25, 1.625], [2.0, 3.75], [4.125, 2.875]]))
+    assert torch.allclose(a[2, 2], torch.tensor([11.65625, 10.1875]))
+
+
+def test_forward_refuses_cpu_and_bad_shapes():
+    from yolov5m_amd import _lib
+    m = _m()
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 3, 100, 64))                      # model.py:211
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.Y5MError):
+            m(torch.zeros(1, 3, 64, 64))
