@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- the headline benchmark: images/sec of the FULL YOLOv5m train step at 640x640.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = forward + build-targets + ComputeLoss + backward + clip_grad_norm_(10) + Adam(L2) on one
+synthetic batch of 64 images per GPU (BASELINE.json configs[2]/[3]; weak scaling), bf16 activations /
+weights with f32 accumulation, f32 master weights and optimizer state, random-init weights, inputs
+resident in HBM before the timed region. Prints ONE JSON line (rank 0).
+
+Extra legs on rank 0 (outside the timed region):
+  * roofline: an eager pass with a HIP-event pair around every launch (events on the launch stream)
+    gives the conv implicit-GEMM family's total time; achieved = algorithmic FLOPs (48.872
+    GFLOP/img forward, the same again minus the stem for the data gradient) / that time, vs the dense
+    bf16 MFMA peak (2.5 PFLOP/s). The same command under `rocprofv3 --kernel-trace --stats` is committed
+    under profiles/.
+  * cpu_baseline ("port"): the CPU oracle's train step (torch fp32, host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak
+FWD_GFLOP_PER_IMAGE_640 = 48.872
+
+
+def cpu_baseline(B=4, size=640, steps=2):
+    """CPU leg: the oracle restatement of the reference path (model fwd, ComputeLoss, autograd bwd,
+    clip, Adam) on the host cores. kind = "port". Bounded: B=4, 1 warm-up + `steps` timed steps."""
+    from oracle import loss_ref, model_ref
+    from yolov5m_amd.utils.synth import synth_state_dict, synth_images, synth_labels
+    torch.manual_seed(0)
+    sd = synth_state_dict()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and "running" not in k and "anchors" not in k}
+    full = dict(sd)
+    full.update(params)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4, weight_decay=5e-4)
+    x = synth_images(B, size, size)
+    t = synth_labels(B, 8)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        out = model_ref.forward(full, x, training=True, new_stats={})
+        loss, _ = loss_ref.compute_loss_ultra(out, t, sd["head.anchors"])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 10.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed train steps (+1 warm-up) of B={B} @ {size}x{size}, torch fp32 on the host "
+                      f"({os.cpu_count()} logical CPUs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from yolov5m_amd import _lib, config, parallel
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    from yolov5m_amd.utils.synth import synth_images, synth_labels
+
+    rank, local, world = parallel.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    _lib.check(_lib.lib().y5m_device_ok(), "y5m_device_ok")
+
+    B, S = args.batch, args.size
+    torch.manual_seed(0)                                   # identical random init on every rank
+    model = YOLOV5m(first_out=config.FIRST_OUT, nc=80, anchors=config.ANCHORS,
+                    ch=(config.FIRST_OUT * 4, config.FIRST_OUT * 8, config.FIRST_OUT * 16)).to(dev)
+    model.compute_dtype = args.dtype
+    model.train()
+    model.flatten_parameters()
+    parallel.broadcast_parameters(model)
+    loss_fn = ComputeLoss(model)
+    hook = parallel.GradAllReduce(world) if world > 1 else None
+    step = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook)
+
+    images = synth_images(B, S, S, seed=f"img/rank{rank}").to(dev)     # resident in HBM before timing
+    targets = synth_labels(B, 8, seed=f"lab/rank{rank}").to(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        lo = step.step(images, targets)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lo = step.step(images, targets)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    final_loss = float(lo[0])
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    out = {
+        "metric": "images/sec (train step, 640x640)", "value": round(value, 2), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"YOLOv5m full train step (fwd + ComputeLoss + bwd + clip + Adam), batch {B}/GPU @ "
+                               f"{S}x{S}, random-init weights, 8 boxes/image (BASELINE.json configs[2]"
+                               + ("/[3]" if world > 1 else "") + ")",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   "final_loss": round(final_loss, 4)},
+    }
+    if not args.no_roofline:
+        fams = {}
+        for _ in range(2):
+            for k, (m_, n_) in step.profile_step(images, targets).items():
+                a, b = fams.get(k, (0.0, 0))
+                fams[k] = (a + m_, b + n_)
+        eng = model._engine_for(images)
+        fwd_flops = eng.conv_flops()
+        stem = eng.layers[0]
+        dgrad_flops = fwd_flops - 2 * stem.M * stem.cout * stem.cin_real * stem.k * stem.k
+        conv_ms, conv_n = fams.get("conv_igemm", (0.0, 1))
+        conv_ms /= 2
+        conv_n //= 2
+        achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
+        wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "conv_igemm_kernel<bf16> (forward conv + data gradient, all launches of one step)",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
+            "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1),
+            "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
+            "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
+        }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,12 @@ from ._lib import (ConvArgs, WgradArgs, EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD,
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 
 
+def _kind(fn, kind):
+    """tag a launch closure with its kernel family (used by the live per-family timing in bench.py)"""
+    fn.kind = kind
+    return fn
+
+
 def _rup(x, m):
     return (x + m - 1) // m * m
 
@@ -59,7 +65,6 @@ class Act:
 
     def as_nchw_f32(self):
         """debug/test helper: dense (B,C,H,W) f32 copy"""
-        t = self.buf.view(-1)[: self.B * self.H * self.W * self.ld + 0] if False else None
         flat = torch.as_strided(self.buf.view(-1), (self.B, self.H, self.W, self.C),
                                 (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), self.off)
         return flat.permute(0, 3, 1, 2).float().contiguous()
@@ -124,6 +129,7 @@ class Engine:
 
         def fn(a=a):
             _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
+        fn.kind = "conv_igemm"
         lst.append((fn, ()))
 
     # ------------------------------------------------------------------ building blocks
@@ -255,7 +261,14 @@ class Engine:
             wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = lay.kk, lay.kk, -lay.pp, 1, -lay.pp, 1
             wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = lay.x.C, lay.cout, lay.M, lay.cout, lay.ldgw, 0
             lay.wgrad_args = wa
-            ops.append((lambda wa=wa: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad"), ()))
+            ops.append((_kind(lambda wa=wa: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad"), "wgrad"), ()))
+            # packed f32 -> reference-layout flat gradient, right away: the layer's slice of the flat
+            # gradient buffer is then final, which is what lets the all-reduce start bucket by bucket
+            mode = 2 if lay.stem else 0
+            ops.append((lambda: _lib.check(
+                L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, lay.cout, lay.cin_real, lay.k, lay.k, mode,
+                                   lay.ldgw, _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad"), ()))
+            self._grad_done.append((lay.name, P["gw"].data_ptr()))
             # data gradient
             if need_dx:
                 xg = lay.x.grad
@@ -282,7 +295,7 @@ class Engine:
                     a.epi, a.act, a.accumulate = EPI_DGRAD, ACT_NONE, acc
                     a.Np = wd.shape[0]
                     lay.dgrad_args.append(a)
-                    ops.append((lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), ()))
+                    ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm"), ()))
             return ops
         self._bwd_stack.append(backward)
 
@@ -381,7 +394,11 @@ class Engine:
                 wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
                 wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = x.C, ldp, M, ldp, x.C, 0
                 lay.wgrad_args = wa
-                ops.append((lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(head)"), ()))
+                ops.append((_kind(lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(head)"), "wgrad"), ()))
+                ops.append((lambda: _lib.check(
+                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, N, x.C, 1, 1, 0, lay.ldgw,
+                                       _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(head)"), ()))
+                self._grad_done.append((lay.name, P["gw"].data_ptr()))
                 acc = 1 if x.gw else 0
                 x.gw = True
                 a = ConvArgs()
@@ -393,7 +410,7 @@ class Engine:
                 a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = x.H, x.W, x.grad.ld, 1, 1, 0, 0
                 a.epi, a.act, a.accumulate, a.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
                 lay.dgrad_args = [a]
-                ops.append((lambda: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(head dgrad)"), ()))
+                ops.append((_kind(lambda: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(head dgrad)"), "conv_igemm"), ()))
                 return ops
             self._bwd_stack.append(backward)
         self.heads.append(lay)
@@ -405,6 +422,7 @@ class Engine:
         B, H, W = self.B, self.H, self.W
         self.pack, self.heads, self._stat_users = [], [], []
         self._gw_floats = 0
+        self._grad_done = []
         first_out = self.model.first_out
         backbone, neck = blocks(first_out)
         # input: NCHW f32 images -> space-to-depth NHWC (no gradient)
@@ -453,32 +471,43 @@ class Engine:
             self.gw = torch.zeros((self._gw_floats,), dtype=torch.float32, device=self.dev)
             # expand the backward stack in reverse order; plan-time gradient-written flags
             self.bwd.append((lambda: self.gw.zero_(), ()))
+            # bwd_marks[i] = (op index after which unit i's parameter gradients are final, unit name,
+            # device address of its weight gradient inside the flat buffer) -- in backward order
+            self.bwd_marks = []
             for mk in reversed(self._bwd_stack):
+                n0 = len(self._grad_done)
                 self.bwd.extend(mk())
-            # packed f32 weight grads -> reference-layout flat gradient
-            for lay in self.layers:
-                P = self.model.pslices[lay.name]
-                mode = 2 if lay.stem else 0
-                self.bwd.append((lambda lay=lay, P=P, mode=mode: _lib.check(
-                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, lay.cout, lay.cin_real, lay.k, lay.k, mode,
-                                       lay.ldgw, _lib.ptr(P["gw"]), _lib.stream_ptr()), "y5m_unpack_wgrad"), ()))
-            for lay in self.heads:
-                P = self.model.pslices[lay.name]
-                N = self.naxs * self.nch
-                self.bwd.append((lambda lay=lay, P=P, N=N: _lib.check(
-                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, N, lay.x.C, 1, 1, 0, lay.ldgw,
-                                       _lib.ptr(P["gw"]), _lib.stream_ptr()), "y5m_unpack_wgrad(head)"), ()))
+                for name, addr in self._grad_done[n0:]:
+                    self.bwd_marks.append((len(self.bwd), name, addr))
 
     # ------------------------------------------------------------------ execution
     @staticmethod
-    def _run(lst):
+    def _run(lst, timeline=None):
+        """Enqueue a launch list. timeline: optional list that receives (kind, start_event, end_event)
+        per op (events recorded on the current stream = the stream the kernels are launched on)."""
         for fn, args in lst:
+            if timeline is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if args:
                 rc = fn(*args, _lib.stream_ptr())
                 if rc != 0:
                     raise _lib.Y5MError(f"native call failed rc={rc}: {_lib.lib().y5m_last_error().decode()}")
             else:
                 fn()
+            if timeline is not None:
+                e1.record()
+                timeline.append((getattr(fn, "kind", getattr(fn, "__name__", "other")), e0, e1))
+
+    def conv_flops(self):
+        """Algorithmic FLOPs (2*MAC on the REAL layer shapes) of one forward
+        pass of all convs at this engine's batch and resolution."""
+        total = 0
+        for lay in self.layers:
+            total += 2 * lay.M * lay.cout * lay.cin_real * lay.k * lay.k
+        for lay in self.heads:
+            total += 2 * lay.x.M * (self.naxs * self.nch) * lay.x.C
+        return total
 
     def forward(self, images=None):
         """images (B,3,H,W) f32 on the device (or already copied into self.x_in). Returns the 3 logits

@@ -1,0 +1,94 @@
+"""Single-node data parallelism: one process per GPU, gradients summed with RCCL over xGMI.
+
+The reference has no distributed code at all; this is the new component BASELINE.json asks
+for. Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, point-to-point, no switch):
+  * every rank holds a full replica; parameters and gradients are ONE flat f32 buffer each
+    (21 190 557 elements, 84.8 MB), so the exchange is a handful of large all-reduces instead of 243
+    small ones -- per-link-bound ring collectives want few, large messages;
+  * gradient convention = SUM over ranks of the local-batch gradients (each rank's loss is already
+    multiplied by its local batch size, ultralytics_loss.py:120), i.e. exactly the gradient of the
+    single-process loss on the concatenated batch up to BatchNorm's per-replica statistics (the
+    reference has no SyncBN to match);
+  * buckets are contiguous ranges of the flat buffer taken in BACKWARD order (head first, stem last);
+    bucket k is all-reduced on the communication stream as soon as the backward segment that finalises
+    it has been enqueued, while the next segment's dgrad/wgrad kernels keep running;
+  * the optimizer then runs identically on every rank (no parameter broadcast after step 0).
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def make_buckets(numel, boundaries, target_bytes=32 << 20):
+    """Split [0, numel) of the flat gradient buffer into buckets in BACKWARD order.
+
+    boundaries: element offsets (ascending) where a bucket may start (= starts of the layer units).
+    Returns [(lo, hi)] ordered from the END of the buffer (head: first gradients to be final) to the
+    start (stem: last), each about target_bytes of f32."""
+    cuts = sorted(set([0, numel] + [b for b in boundaries if 0 < b < numel]))
+    target = max(1, target_bytes // 4)
+    out = []
+    hi = numel
+    i = len(cuts) - 2
+    while hi > 0:
+        lo = cuts[i]
+        while i > 0 and hi - lo < target:
+            i -= 1
+            lo = cuts[i]
+        out.append((lo, hi))
+        hi = lo
+        i -= 1
+    return out
+
+
+class GradAllReduce:
+    """SUM all-reduce of a flat gradient buffer, whole or bucket by bucket."""
+
+    def __init__(self, world_size=None, group=None):
+        self.group = group
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.pending = []
+
+    def __call__(self, flat):
+        """blocking (stream-ordered on GPU) all-reduce of the whole buffer"""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def launch(self, flat, lo, hi):
+        """asynchronous all-reduce of flat[lo:hi] (call after the producing kernels were enqueued)"""
+        if self.world > 1:
+            self.pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """make every replica start from rank `src`'s parameters and BN buffers"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if getattr(model, "flat_params", None) is not None:
+        dist.broadcast(model.flat_params, src=src, group=group)
+        dist.broadcast(model._flat_stats, src=src, group=group)
+    else:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src, group=group)

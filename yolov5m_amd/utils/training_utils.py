@@ -91,43 +91,53 @@ class NativeTrainStep:
         self._key = None
         self._ws = None
 
-    # the launch list of one step (everything after the inputs are in place)
-    def _enqueue(self, eng):
+    # forward + build-targets + loss (+ d loss / d logits) + backward: everything before the optimizer
+    def _enqueue_fb(self, eng, timeline=None):
         from ..ultralytics_loss import _Workspace
         L = _lib.lib()
-        model, lf = self.model, self.loss_fn
+        lf = self.loss_fn
         st = _lib.stream_ptr()
-        outs = eng.forward(None)
+        eng._run(eng.pack, timeline)
+        eng._run(eng.fwd, timeline)
+        outs = eng.outs
         B = eng.B
         shapes = [(o.shape[2], o.shape[3]) for o in outs]
         if self._ws is None or self._ws.key != (B, eng.naxs, tuple(shapes), self.nt_max):
             self._ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
         ws = self._ws
-        _lib.check(L.y5m_build_targets(_lib.ptr(self.targets), 0, _lib.ptr(self.d_nt), self.nt_max,
-                                       _lib.ptr(lf.anchors), eng.naxs, ws.ny, ws.nx, float(lf.anchor_t), ws.tg,
-                                       _lib.ptr(ws.bt_ws), ws.bt_ws_bytes, st), "y5m_build_targets")
         grads = eng.head_grad_buffers()
-        _lib.check(L.y5m_compute_loss(_lib.ptr_array(outs), _lib.ptr_array(grads), B, eng.naxs, ws.ny, ws.nx, lf.nc,
-                                      ws.tg, self.nt_max, _lib.float_array(lf.balance), float(lf.lambda_box),
-                                      float(lf.lambda_obj), float(lf.lambda_class), _lib.ptr(ws.loss_out),
-                                      _lib.ptr(ws.loss_ws), ws.loss_ws_bytes, st), "y5m_compute_loss")
-        self.loss_out = ws.loss_out
-        eng.backward(None)
-        if self.grad_hook is not None:
-            self.grad_hook(model.flat_grads)
-        self._optimizer(st)
 
-    def _optimizer(self, st):
+        def loss_ops():
+            _lib.check(L.y5m_build_targets(_lib.ptr(self.targets), 0, _lib.ptr(self.d_nt), self.nt_max,
+                                           _lib.ptr(lf.anchors), eng.naxs, ws.ny, ws.nx, float(lf.anchor_t), ws.tg,
+                                           _lib.ptr(ws.bt_ws), ws.bt_ws_bytes, st), "y5m_build_targets")
+            _lib.check(L.y5m_compute_loss(_lib.ptr_array(outs), _lib.ptr_array(grads), B, eng.naxs, ws.ny, ws.nx,
+                                          lf.nc, ws.tg, self.nt_max, _lib.float_array(lf.balance),
+                                          float(lf.lambda_box), float(lf.lambda_obj), float(lf.lambda_class),
+                                          _lib.ptr(ws.loss_out), _lib.ptr(ws.loss_ws), ws.loss_ws_bytes, st),
+                       "y5m_compute_loss")
+        loss_ops.kind = "loss"
+        eng._run([(loss_ops, ())], timeline)
+        self.loss_out = ws.loss_out
+        eng._run(eng.bwd, timeline)
+
+    def _optimizer(self, timeline=None):
         L = _lib.lib()
         model = self.model
         n = model.flat_params.numel()
-        self.d_step += 1
-        _lib.check(L.y5m_grad_norm(_lib.ptr(model.flat_grads), n, _lib.ptr(self.gnorm), _lib.ptr(self.aws),
-                                   self.aws_bytes, st), "y5m_grad_norm")
-        _lib.check(L.y5m_adam_step(_lib.ptr(model.flat_params), _lib.ptr(model.flat_grads), _lib.ptr(self.m),
-                                   _lib.ptr(self.v), n, _lib.ptr(self.gnorm), float(self.max_norm), float(self.lr),
-                                   float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
-                                   _lib.ptr(self.d_step), st), "y5m_adam_step")
+        st = _lib.stream_ptr()
+
+        def opt_ops():
+            self.d_step.add_(1)
+            _lib.check(L.y5m_grad_norm(_lib.ptr(model.flat_grads), n, _lib.ptr(self.gnorm), _lib.ptr(self.aws),
+                                       self.aws_bytes, st), "y5m_grad_norm")
+            _lib.check(L.y5m_adam_step(_lib.ptr(model.flat_params), _lib.ptr(model.flat_grads), _lib.ptr(self.m),
+                                       _lib.ptr(self.v), n, _lib.ptr(self.gnorm), float(self.max_norm),
+                                       float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                       float(self.wd), _lib.ptr(self.d_step), st), "y5m_adam_step")
+        opt_ops.kind = "optimizer"
+        from ..engine import Engine
+        Engine._run([(opt_ops, ())], timeline)
 
     def load_inputs(self, images, targets):
         eng = self.model._engine_for(images)
@@ -141,21 +151,49 @@ class NativeTrainStep:
         return eng
 
     def step(self, images, targets):
-        """Returns the device tensor [loss*bs, lbox, lobj, lcls] of THIS step (no host sync)."""
+        """Returns the device tensor [loss*bs, lbox, lobj, lcls] of THIS step (no host sync).
+        With use_graph the step is two captured hipGraphs (forward+loss+backward | optimizer) replayed
+        back to back; grad_hook (the RCCL all-reduce) runs between them on the same stream."""
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
         key = (id(eng),)
         if not self.use_graph:
-            self._enqueue(eng)
+            self._enqueue_fb(eng)
+            if self.grad_hook is not None:
+                self.grad_hook(self.model.flat_grads)
+            self._optimizer()
             return self.loss_out
         if self._graph is None or self._key != key:
-            # warm-up once eagerly (module loading, attribute setting), then capture
-            self._enqueue(eng)
+            # one eager warm-up step (module loading, kernel attributes), then capture
+            self._enqueue_fb(eng)
+            if self.grad_hook is not None:
+                self.grad_hook(self.model.flat_grads)
+            self._optimizer()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue(eng)
-            self._graph, self._key = g, key
-            return self.loss_out
-        self._graph.replay()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._enqueue_fb(eng)
+            with torch.cuda.graph(g2):
+                self._optimizer()
+            self._graph, self._key = (g1, g2), key
+        g1, g2 = self._graph
+        g1.replay()
+        if self.grad_hook is not None:
+            self.grad_hook(self.model.flat_grads)
+        g2.replay()
         return self.loss_out
+
+    def profile_step(self, images, targets):
+        """One EAGER step with a HIP event pair around every launch (recorded on the launch stream).
+        Returns {kernel family: (total ms, launches)}."""
+        eng = self.load_inputs(images, targets)
+        self.model._nbt += 1
+        tl = []
+        self._enqueue_fb(eng, tl)
+        self._optimizer(tl)
+        torch.cuda.synchronize()
+        fam = {}
+        for kind, e0, e1 in tl:
+            ms, n = fam.get(kind, (0.0, 0))
+            fam[kind] = (ms + e0.elapsed_time(e1), n + 1)
+        return fam
