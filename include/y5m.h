@@ -185,10 +185,11 @@ int y5m_s2d_input(const float* img, int B, int H, int W, void* out, int dtype, v
 /* BatchNorm2d(eps=1e-3, momentum=0.03) of CBL (model.py:17), training mode: finalise the batch
  * statistics from the conv epilogue partials, update running stats (unbiased var), emit the fused
  * scale/shift and the saved mean / invstd for backward. */
+size_t y5m_bn_finalize_workspace_bytes(int Np);
 int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, int64_t count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* mean_out, float* invstd_out, int update_running,
-                    void* stream);
+                    void* ws, size_t ws_bytes, void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int y5m_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                 float eps, int C, float* scale, float* shift, void* stream);
@@ -212,8 +213,9 @@ int y5m_upsample2x_bwd(const void* gout, int ldg, int B, int H, int W, int C, vo
 /* SPPF (model.py:103-112): the three cascaded MaxPool2d(5,1,2) in one launch; backward per level */
 int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, int dtype,
                   void* stream);
+size_t y5m_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C);
 int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
-                     int ldgin, int accumulate, int dtype, void* stream);
+                     int ldgin, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
 /* d(loss)/d(logits) (B,naxs,ny,nx,nch) f32 -> head conv output gradient [B*ny*nx][ldp] + bias grad */
 int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
                        float* dbias, int dtype, void* stream);

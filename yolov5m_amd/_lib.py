@@ -75,8 +75,10 @@ _SIGS = {
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "y5m_bn_finalize_workspace_bytes": (c_size_t, [c_int]),
     "y5m_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                c_void_p]),
     "y5m_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "y5m_bn_act": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int,
                            c_int, c_int, c_void_p]),
@@ -90,8 +92,9 @@ _SIGS = {
                                    c_void_p]),
     "y5m_sppf_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                               c_void_p]),
+    "y5m_maxpool5_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "y5m_maxpool5_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                 c_int, c_int, c_void_p]),
+                                 c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "y5m_head_grad_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                    c_void_p]),
     "y5m_adam_workspace_bytes": (c_size_t, []),

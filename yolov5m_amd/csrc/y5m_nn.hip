@@ -168,13 +168,55 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+// stage 1 of long column reductions: in [R][2][ld] -> out [S][2][ld], S = gridDim.x row splits.
+// Threads run along channels (coalesced 256-byte rows), 4 row lanes per block, fixed order.
+#define CR_SPLITS 256
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ in, int R, int ld, int C,
+                                                       float* __restrict__ out) {
+    __shared__ float sm[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int chunk = (R + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * chunk, r1 = min(R, r0 + chunk);
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            a += in[((size_t)r * 2 + 0) * ld + c];
+            b += in[((size_t)r * 2 + 1) * ld + c];
+        }
+    sm[0][rl][cl] = a; sm[1][rl][cl] = b;
+    __syncthreads();
+    if (rl < 2 && c < C) {
+        const float t = (sm[rl][0][cl] + sm[rl][1][cl]) + (sm[rl][2][cl] + sm[rl][3][cl]);
+        out[((size_t)blockIdx.x * 2 + rl) * ld + c] = t;
+    }
+}
+
+// returns the (pointer, rows) the finalize kernel should read: either the input or the stage-1 output
+static int colreduce_if_long(const float*& part, int& R, int ld, int C, float* ws, hipStream_t st) {
+    if (R <= 2 * CR_SPLITS) return Y5M_OK;
+    hipLaunchKernelGGL(colreduce_kernel, dim3(CR_SPLITS, (unsigned)((C + 63) / 64)), dim3(256), 0, st, part, R, ld, C, ws);
+    Y5M_CHECK_LAUNCH("colreduce_kernel");
+    part = ws;
+    R = CR_SPLITS;
+    return Y5M_OK;
+}
+
+extern "C" size_t y5m_bn_finalize_workspace_bytes(int Np) { return (size_t)CR_SPLITS * 2 * (size_t)Np * sizeof(float) + 256; }
+
 extern "C" int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, int64_t count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* mean_out, float* invstd_out, int update_running,
-                               void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, y5m_stream(stream), stats,
-                       tiles_m, Np, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
-                       mean_out, invstd_out, update_running);
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (ws_bytes < y5m_bn_finalize_workspace_bytes(Np)) { y5m_set_error("bn_finalize ws too small"); return Y5M_EWS; }
+    hipStream_t st = y5m_stream(stream);
+    const float* part = stats;
+    int R = tiles_m;
+    const int rc = colreduce_if_long(part, R, Np, C, reinterpret_cast<float*>(ws), st);
+    if (rc != Y5M_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, part, R, Np, C,
+                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out,
+                       invstd_out, update_running);
     Y5M_CHECK_LAUNCH("bn_finalize_kernel");
     return Y5M_OK;
 }
@@ -289,7 +331,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C,
+// sums -> (sbeta, sgamma) for the apply pass AND the parameter gradients (written or accumulated)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C,
+                                                             float* __restrict__ sgamma, float* __restrict__ sbeta,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int accumulate) {
     __shared__ double s1[16][17], s2[16][17];
@@ -298,15 +342,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     double a = 0.0, b = 0.0;
     if (c < C)
         for (int t = rs; t < nblk; t += 16) {
-            a += (double)part[((size_t)t * 2 + 0) * C + c];
-            b += (double)part[((size_t)t * 2 + 1) * C + c];
+            a += (double)part[((size_t)t * 2 + 0) * ld + c];
+            b += (double)part[((size_t)t * 2 + 1) * ld + c];
         }
     s1[rs][cs] = a; s2[rs][cs] = b;
     __syncthreads();
     if (rs == 0 && c < C) {
         for (int r = 1; r < 16; ++r) { a += s1[r][cs]; b += s2[r][cs]; }
-        if (accumulate) { dbeta[c] += (float)a; dgamma[c] += (float)b; }
-        else { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+        sbeta[c] = (float)a; sgamma[c] = (float)b;
+        if (dgamma && dbeta) {
+            if (accumulate) { dbeta[c] += (float)a; dgamma[c] += (float)b; }
+            else { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+        }
     }
 }
 
@@ -339,7 +386,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T*
 
 extern "C" size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C) {
     const size_t nblk = (size_t)((M + BNR_ROWS - 1) / BNR_ROWS);
-    return y5m_align(nblk * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + 256;
+    return y5m_align(nblk * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + y5m_align((size_t)CR_SPLITS * 2 * C * 4) + 256;
 }
 
 // Full BN+SiLU backward of one CBL: param grads (dgamma, dbeta: accumulate flag) and dy.
@@ -349,31 +396,23 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
                           int dtype, void* stream) {
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     if (ws_bytes < y5m_bn_bwd_workspace_bytes(M, C)) { y5m_set_error("bn_bwd ws too small"); return Y5M_EWS; }
-    const int nblk = (int)((M + BNR_ROWS - 1) / BNR_ROWS);
+    int nblk = (int)((M + BNR_ROWS - 1) / BNR_ROWS);
     float* part = reinterpret_cast<float*>(ws);
-    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + y5m_align((size_t)nblk * 2 * C * 4));
+    char* p1 = reinterpret_cast<char*>(ws) + y5m_align((size_t)nblk * 2 * C * 4);
+    float* sums = reinterpret_cast<float*>(p1);
+    float* stage = reinterpret_cast<float*>(p1 + y5m_align((size_t)2 * C * 4));
     float* sbeta = sums, *sgamma = sums + C;
     hipStream_t st = y5m_stream(stream);
     const dim3 rgrid((unsigned)nblk, (unsigned)((C + 63) / 64));
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, rgrid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y,
                                          ldy, scale, shift, mean, invstd, M, C, act, part);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, part, nblk, C, sgamma,
-                       sbeta, 0);
+    const float* pp = part;
+    const int rc = colreduce_if_long(pp, nblk, C, C, stage, st);
+    if (rc != Y5M_OK) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, pp, nblk, C, C, sgamma,
+                       sbeta, dgamma, dbeta, accumulate_param_grads);
     Y5M_CHECK_LAUNCH("bn_bwd_finalize_kernel");
-    // parameter gradients (d gamma, d beta) = the same sums
-    if (dgamma && dbeta) {
-        if (accumulate_param_grads) {
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, part, nblk, C,
-                               dgamma, dbeta, 1);
-            Y5M_CHECK_LAUNCH("bn_bwd_finalize_kernel(acc)");
-        } else {
-            if (hipMemcpyAsync(dbeta, sbeta, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-                hipMemcpyAsync(dgamma, sgamma, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                y5m_set_error("bn_bwd memcpy"); return Y5M_ELAUNCH;
-            }
-        }
-    }
     const int64_t n = M * (C / 8);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)dz, lddz,
                                          (const T*)y, ldy, scale, shift, mean, invstd, sbeta, sgamma, 1.0f / (float)M,
@@ -523,9 +562,38 @@ extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, 
 
 // backward of ONE MaxPool2d(5,1,2): gin[i] (+)= sum over outputs o whose window argmax is i of g[o].
 // argmax = first maximum in (row, col) scan order, as ATen's max_pool2d_with_indices.
+// Pass 1 stores, per output, the window-relative position (0..24) of its argmax; pass 2 gathers.
 template <typename T>
-__global__ void maxpool5_bwd_kernel(const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg, int B, int H,
-                                    int W, int C, T* __restrict__ gin, int ldgin, int accumulate) {
+__global__ void maxpool5_argmax_kernel(const T* __restrict__ z, int ldz, int B, int H, int W, int C,
+                                       unsigned char* __restrict__ code) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * H * W * C;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int ox = (int)(t % W); t /= W;
+    const int oy = (int)(t % H);
+    const int b = (int)(t / H);
+    const T* zb = z + (size_t)b * H * W * ldz + c;
+    float best = -INFINITY;
+    int bc = -1;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const int wy = oy + dy - 2;
+        if (wy < 0 || wy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            const int wx = ox + dx - 2;
+            if (wx < 0 || wx >= W) continue;
+            const float v = to_f32<T>(zb[((size_t)wy * W + wx) * ldz]);
+            if (v > best || bc < 0) { best = v; bc = dy * 5 + dx; }
+        }
+    }
+    code[i] = (unsigned char)bc;
+}
+template <typename T>
+__global__ void maxpool5_gather_kernel(const unsigned char* __restrict__ code, const T* __restrict__ g, int ldg, int B,
+                                       int H, int W, int C, T* __restrict__ gin, int ldgin, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)B * H * W * C;
     if (i >= n) return;
@@ -534,36 +602,37 @@ __global__ void maxpool5_bwd_kernel(const T* __restrict__ z, int ldz, const T* _
     const int xx = (int)(t % W); t /= W;
     const int yy = (int)(t % H);
     const int b = (int)(t / H);
-    const T* zb = z + (size_t)b * H * W * ldz + c;
     float acc = 0.f;
-    for (int oy = yy - 2; oy <= yy + 2; ++oy) {
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int oy = yy + dy;
         if (oy < 0 || oy >= H) continue;
-        for (int ox = xx - 2; ox <= xx + 2; ++ox) {
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int ox = xx + dx;
             if (ox < 0 || ox >= W) continue;
-            // argmax of window centred at (oy, ox)
-            float best = -INFINITY;
-            int by = -1, bx = -1;
-            for (int wy = oy - 2; wy <= oy + 2; ++wy) {
-                if (wy < 0 || wy >= H) continue;
-                for (int wx = ox - 2; wx <= ox + 2; ++wx) {
-                    if (wx < 0 || wx >= W) continue;
-                    const float v = to_f32<T>(zb[((size_t)wy * W + wx) * ldz]);
-                    if (v > best || by < 0) { best = v; by = wy; bx = wx; }
-                }
-            }
-            if (by == yy && bx == xx) acc += to_f32<T>(g[(((size_t)b * H + oy) * W + ox) * ldg + c]);
+            const size_t o = ((size_t)b * H + oy) * W + ox;
+            // (yy,xx) sits at window position (2-dy, 2-dx) of output (oy,ox)
+            if (code[o * C + c] == (unsigned char)((2 - dy) * 5 + (2 - dx))) acc += to_f32<T>(g[o * ldg + c]);
         }
     }
     T* d = gin + (((size_t)b * H + yy) * W + xx) * ldgin + c;
     if (accumulate) acc += to_f32<T>(*d);
     *d = from_f32<T>(acc);
 }
+extern "C" size_t y5m_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C) { return (size_t)B * H * W * C + 256; }
 extern "C" int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
-                                int ldgin, int accumulate, int dtype, void* stream) {
+                                int ldgin, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream) {
     const int64_t n = (int64_t)B * H * W * C;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
-                                         (const T*)z, ldz, (const T*)g, ldg, B, H, W, C, (T*)gin, ldgin, accumulate);)
-    Y5M_CHECK_LAUNCH("maxpool5_bwd_kernel");
+    if (ws_bytes < y5m_maxpool5_bwd_workspace_bytes(B, H, W, C)) { y5m_set_error("maxpool5_bwd ws too small"); return Y5M_EWS; }
+    unsigned char* code = reinterpret_cast<unsigned char*>(ws);
+    hipStream_t st = y5m_stream(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_argmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)z, ldz, B,
+                                         H, W, C, code);)
+    Y5M_CHECK_LAUNCH("maxpool5_argmax_kernel");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_gather_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, code, (const T*)g,
+                                         ldg, B, H, W, C, (T*)gin, ldgin, accumulate);)
+    Y5M_CHECK_LAUNCH("maxpool5_gather_kernel");
     return Y5M_OK;
 }
 
@@ -571,50 +640,41 @@ extern "C" int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, 
 // head gradient: d(loss)/d(logits) f32 (B,naxs,ny,nx,nch) -> dY [M=B*ny*nx][ldp] in compute dtype
 // (channel n = a*nch + c, columns >= naxs*nch zero) + bias gradient (column sums)
 // =================================================================================================
+// One block walks whole pixel rows: thread = output column (channel n = a*nch + c). The three
+// 85-float runs of a pixel are read coalesced, the packed row is written coalesced, and each thread
+// keeps the column sum (= bias gradient) in a register: one atomic per column per block.
 template <typename T>
-__global__ void head_grad_pack_kernel(const float* __restrict__ dl, int B, int naxs, int ny, int nx, int nch,
-                                      T* __restrict__ dyp, int ldp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)B * ny * nx * ldp;
-    if (i >= n) return;
-    const int col = (int)(i % ldp);
-    const int64_t m = i / ldp;
-    float v = 0.f;
-    if (col < naxs * nch) {
-        const int a = col / nch, c = col - a * nch;
-        const int64_t pix = m % ((int64_t)ny * nx);
-        const int64_t b = m / ((int64_t)ny * nx);
-        v = dl[((b * naxs + a) * (int64_t)ny * nx + pix) * nch + c];
-    }
-    dyp[i] = from_f32<T>(v);
-}
-__global__ __launch_bounds__(128) void head_bias_grad_kernel(const float* __restrict__ dl, int B, int naxs, int64_t hw,
-                                                            int nch, float* __restrict__ dbias) {
-    // grid (naxs, splits); thread c walks rows (b, pix) of anchor a: coalesced along c
-    const int a = blockIdx.x, c = threadIdx.x;
-    if (c >= nch) return;
-    const int64_t rows = (int64_t)B * hw;
+__global__ __launch_bounds__(256) void head_grad_pack_kernel(const float* __restrict__ dl, int B, int naxs, int64_t hw,
+                                                            int nch, T* __restrict__ dyp, int ldp,
+                                                            float* __restrict__ dbias) {
+    const int col = threadIdx.x;
+    const int64_t M = (int64_t)B * hw;
+    const int N = naxs * nch;
+    const int a = col / nch, c = col - a * nch;
     float acc = 0.f;
-    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-        const int64_t b = r / hw, pix = r - b * hw;
-        acc += dl[((b * naxs + a) * hw + pix) * nch + c];
+    if (col < ldp) {
+        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+            float v = 0.f;
+            if (col < N) {
+                const int64_t b = m / hw, pix = m - b * hw;
+                v = dl[((b * naxs + a) * hw + pix) * nch + c];
+            }
+            dyp[m * ldp + col] = from_f32<T>(v);
+            acc += v;
+        }
+        if (dbias && col < N) atomicAdd(&dbias[col], acc);
     }
-    atomicAdd(&dbias[a * nch + c], acc);
 }
 extern "C" int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
                                   float* dbias, int dtype, void* stream) {
-    Y5M_REQUIRE(nch <= 128 && ldp >= naxs * nch, "head dims");
-    const int64_t n = (int64_t)B * ny * nx * ldp;
+    Y5M_REQUIRE(ldp <= 256 && ldp >= naxs * nch, "head dims: naxs*nch <= ldp <= 256");
     hipStream_t st = y5m_stream(stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, dlogits, B, naxs,
-                                         ny, nx, nch, (T*)dyp, ldp);)
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)naxs * nch * 4, st) != hipSuccess) { y5m_set_error("memset dbias"); return Y5M_ELAUNCH; }
+    const int64_t M = (int64_t)B * ny * nx;
+    const unsigned grid = (unsigned)(M < 4096 ? M : 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_kernel<T>, dim3(grid), dim3(256), 0, st, dlogits, B, naxs,
+                                         (int64_t)ny * nx, nch, (T*)dyp, ldp, dbias);)
     Y5M_CHECK_LAUNCH("head_grad_pack_kernel");
-    if (dbias) {
-        if (hipMemsetAsync(dbias, 0, (size_t)naxs * nch * 4, st) != hipSuccess) { y5m_set_error("memset dbias"); return Y5M_ELAUNCH; }
-        hipLaunchKernelGGL(head_bias_grad_kernel, dim3((unsigned)naxs, 64), dim3(128), 0, st, dlogits, B, naxs,
-                           (int64_t)ny * nx, nch, dbias);
-        Y5M_CHECK_LAUNCH("head_bias_grad_kernel");
-    }
     return Y5M_OK;
 }
 

@@ -174,7 +174,8 @@ class Engine:
                 _lib.check(L.y5m_bn_finalize(_lib.ptr(self.stats), tiles_m, Np, lay.cout, M, _lib.ptr(P["g"]),
                                              _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
                                              BN_MOMENTUM, BN_EPS, bn[0].data_ptr(), bn[1].data_ptr(),
-                                             bn[2].data_ptr(), bn[3].data_ptr(), 1, st()), "y5m_bn_finalize")
+                                             bn[2].data_ptr(), bn[3].data_ptr(), 1, _lib.ptr(self.finws),
+                                             self.finws.numel(), st()), "y5m_bn_finalize")
             self.fwd.append((finalize, ()))
 
             def apply(lay=lay, bn=bn, dest=dest, res=res, M=M):
@@ -326,6 +327,8 @@ class Engine:
         self.fwd.append((lambda: _lib.check(L.y5m_sppf_pool(sl[0].ptr, cat.ld, x.B, x.H, x.W, c_, sl[1].ptr, sl[2].ptr,
                                                            sl[3].ptr, dt, st()), "y5m_sppf_pool"), ()))
         if self.training:
+            poolws = torch.zeros((L.y5m_maxpool5_bwd_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
+
             def backward():
                 ops = []
                 g = [s.grad for s in sl]
@@ -333,7 +336,8 @@ class Engine:
                 for lvl in (2, 1, 0):
                     ops.append((lambda lvl=lvl: _lib.check(
                         L.y5m_maxpool5_bwd(sl[lvl].ptr, cat.ld, g[lvl + 1].ptr, g[lvl + 1].ld, x.B, x.H, x.W, c_,
-                                           g[lvl].ptr, g[lvl].ld, 1, dt, st()), "y5m_maxpool5_bwd"), ()))
+                                           g[lvl].ptr, g[lvl].ld, 1, _lib.ptr(poolws), poolws.numel(), dt, st()),
+                        "y5m_maxpool5_bwd"), ()))
                 return ops
             self._bwd_stack.append(backward)
         return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0)
@@ -463,6 +467,7 @@ class Engine:
         self.outs = [self._head(0, n3), self._head(1, n5), self._head(2, n7)]
         # shared scratch
         self.stats = torch.zeros((max(self._stats_floats, 1),), dtype=torch.float32, device=self.dev)
+        self.finws = torch.zeros((L.y5m_bn_finalize_workspace_bytes(16 * first_out + 96),), dtype=torch.uint8, device=self.dev)
         for a in self._stat_users:
             a.stats = self.stats.data_ptr()
         if self.training:
