@@ -176,6 +176,15 @@ int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
 int y5m_pack_weights(const float* src, int Cout, int Cin, int KH, int KW, int mode, int kh0, int khs,
                      int th, int kw0, int kws, int tw, void* dst, int rows_p, int Kp, int cstride,
                      int dtype, void* stream);   /* cstride: per-tap channel stride (0 = dense) */
+/* the same for a whole step in ONE launch: a DEVICE table of jobs (start = running element offset,
+ * job j covers [start_j, start_j + rows_p*Kp)); total = sum of rows_p*Kp */
+typedef struct {
+    const float* src;
+    void* dst;
+    int32_t Cout, Cin, KH, KW, mode, kh0, khs, th, kw0, kws, tw, rows_p, Kp, cstride;
+    int64_t start;
+} y5m_pack_job;
+int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t total, int dtype, void* stream);
 /* packed f32 gradient [Cout][ldg] (mode 0 or 2 ordering) -> [Cout][Cin][KH][KW] */
 int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
                      void* stream);

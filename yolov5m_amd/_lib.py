@@ -43,6 +43,13 @@ class WgradArgs(ctypes.Structure):
                                       "dw0", "dws", "C", "N", "M", "lddy", "lddw", "ksplit", "tiles_n", "tiles_c")])
 
 
+class PackJob(ctypes.Structure):
+    """mirror of y5m_pack_job (include/y5m.h)"""
+    _fields_ = ([("src", c_void_p), ("dst", c_void_p)] +
+                [(n, c_int) for n in ("Cout", "Cin", "KH", "KW", "mode", "kh0", "khs", "th", "kw0", "kws", "tw",
+                                      "rows_p", "Kp", "cstride")] + [("start", c_int64)])
+
+
 EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD, EPI_DGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_SILU = 0, 1
 F32, BF16 = 0, 1
@@ -73,6 +80,7 @@ _SIGS = {
     "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "y5m_pack_weights_batched": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),
     "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y5m_bn_finalize_workspace_bytes": (c_size_t, [c_int]),

@@ -2,6 +2,7 @@
 // See y5m_conv.h for the tiling / layout description.
 #include "y5m_conv.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 template <typename T, int WM, int WN, int MF, int NF>
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
             }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, nl = tid - which * BN;
+        for (int tt = tid; tt < 2 * BN; tt += CV_THREADS) {
+            const int which = tt / BN, nl = tt - which * BN;
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + nl];
@@ -255,7 +256,15 @@ static int launch_conv(ConvParams& P, hipStream_t st) {
     return Y5M_OK;
 }
 
-extern "C" int y5m_conv_tile_n(int N) { return (N <= 48) ? 48 : 96; }
+// Channel tile: 48 for the 48-channel layers, 192 (wave tile 64x96: half the LDS bytes per MFMA of the
+// 96 tile) when N is a multiple of 192, else 96. Y5M_CONV_BN192=0 disables the wide tile (A/B runs).
+static int g_bn192 = -1;
+extern "C" int y5m_conv_tile_n(int N) {
+    if (g_bn192 < 0) { const char* e = getenv("Y5M_CONV_BN192"); g_bn192 = (e && e[0] == '0') ? 0 : 1; }
+    if (N <= 48) return 48;
+    if (g_bn192 && N % 192 == 0) return 192;
+    return 96;
+}
 
 extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     ConvParams P;
@@ -273,9 +282,11 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     hipStream_t st = y5m_stream(stream);
     if (dtype == Y5M_BF16) {
         if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
+        if (BN == 192) return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
         return launch_conv<bf16_t, 2, 2, 4, 3>(P, st);
     } else {
         if (BN == 48) return launch_conv<float, 4, 1, 2, 3>(P, st);
+        if (BN == 192) return launch_conv<float, 2, 2, 4, 6>(P, st);
         return launch_conv<float, 2, 2, 4, 3>(P, st);
     }
 }

@@ -42,10 +42,16 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wn = wid & 1, wc = wid >> 1;
-    int bid = blockIdx.x;
-    const int ksp = bid % P.ksplit; bid /= P.ksplit;
+    // Block order: all (tap, c-tile, n-tile) blocks of ONE pixel range are consecutive logical ids and
+    // (XCD-aware remap: hardware block b runs on XCD b%8) land on the same XCD, so the 9 taps re-read
+    // the same dY / shifted-X pixels from that XCD's L2 instead of from HBM.
+    const int nblk = gridDim.x, hb = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = hb & 7;
+    int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hb >> 3);
     const int tap = bid % (P.th * P.tw); bid /= (P.th * P.tw);
-    const int ct = bid % P.tiles_c, nt = bid / P.tiles_c;
+    const int ct = bid % P.tiles_c; bid /= P.tiles_c;
+    const int nt = bid % P.tiles_n;
+    const int ksp = bid / P.tiles_n;
     const int n0 = nt * WG_TN, c0 = ct * WG_TC;
     const int ta = tap / P.tw, tb = tap - ta * P.tw;
     const int dh = P.dh0 + ta * P.dhs, dw = P.dw0 + tb * P.dws;

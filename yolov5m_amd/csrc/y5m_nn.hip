@@ -60,6 +60,52 @@ extern "C" int y5m_pack_weights(const float* src, int Cout, int Cin, int KH, int
     return Y5M_OK;
 }
 
+// All weight packs of a step in ONE launch: a device table of jobs with element-count prefixes;
+// each thread finds its job by binary search (the table is ~200 entries, L2/scalar-cache resident).
+template <typename T>
+__device__ __forceinline__ void pack_one(const y5m_pack_job& J, int64_t i) {
+    const int r = (int)(i / J.Kp), k = (int)(i - (int64_t)r * J.Kp);
+    float v = 0.0f;
+    if (J.mode == 2) {
+        const int tap = k >> 4, cc = k & 15;
+        if (r < J.Cout && tap < 9 && cc < 12) {
+            const int a = tap / 3, b = tap - 3 * a;
+            const int dyx = cc / 3, c = cc - 3 * dyx;
+            v = J.src[((r * J.Cin + c) * J.KH + (2 * a + (dyx >> 1))) * J.KW + (2 * b + (dyx & 1))];
+        }
+    } else {
+        const int Cc = J.mode == 0 ? J.Cin : J.Cout;
+        const int Cs = J.cstride > 0 ? J.cstride : Cc;
+        const int R = J.mode == 0 ? J.Cout : J.Cin;
+        const int tap = k / Cs, cc = k - tap * Cs;
+        if (r < R && tap < J.th * J.tw && cc < Cc) {
+            const int ta = tap / J.tw, tb = tap - ta * J.tw;
+            const int kh = J.kh0 + ta * J.khs, kw = J.kw0 + tb * J.kws;
+            const int co = J.mode == 0 ? r : cc, ci = J.mode == 0 ? cc : r;
+            v = J.src[((co * J.Cin + ci) * J.KH + kh) * J.KW + kw];
+        }
+    }
+    reinterpret_cast<T*>(J.dst)[i] = from_f32<T>(v);
+}
+template <typename T>
+__global__ void pack_batched_kernel(const y5m_pack_job* __restrict__ jobs, int njobs, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    pack_one<T>(jobs[lo], i - jobs[lo].start);
+}
+extern "C" int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t total, int dtype, void* stream) {
+    if (njobs <= 0 || total <= 0) return Y5M_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(ew_blocks(total)), dim3(EW_T), 0, y5m_stream(stream),
+                                         d_jobs, njobs, total);)
+    Y5M_CHECK_LAUNCH("pack_batched_kernel");
+    return Y5M_OK;
+}
+
 // packed weight gradient f32 [N][taps][Cc] -> reference layout [Cout][Cin][KH][KW] (mode as above)
 __global__ void unpack_wgrad_kernel(const float* __restrict__ gp, int Cout, int Cin, int KH, int KW, int mode,
                                     int ldg, float* __restrict__ dst) {

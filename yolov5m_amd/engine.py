@@ -465,6 +465,7 @@ class Engine:
         self._cbl("neck.6", n5, 8 * f, 3, 2, 1, dest=c4a)
         n7 = self._c3("neck.7", cat4, 16 * f, 0.5, 2, False)
         self.outs = [self._head(0, n3), self._head(1, n5), self._head(2, n7)]
+        self._batch_packs()
         # shared scratch
         self.stats = torch.zeros((max(self._stats_floats, 1),), dtype=torch.float32, device=self.dev)
         self.finws = torch.zeros((L.y5m_bn_finalize_workspace_bytes(16 * first_out + 96),), dtype=torch.uint8, device=self.dev)
@@ -484,6 +485,33 @@ class Engine:
                 self.bwd.extend(mk())
                 for name, addr in self._grad_done[n0:]:
                     self.bwd_marks.append((len(self.bwd), name, addr))
+
+    def _batch_packs(self):
+        """Fold every y5m_pack_weights entry of self.pack into ONE launch over a device job table."""
+        L, dt = self.L, self.dtype
+        jobs, rest, total = [], [], 0
+        for fn, args in self.pack:
+            if fn is L.y5m_pack_weights:
+                j = _lib.PackJob()
+                (src, j.Cout, j.Cin, j.KH, j.KW, j.mode, j.kh0, j.khs, j.th, j.kw0, j.kws, j.tw, dst, j.rows_p, j.Kp,
+                 j.cstride, _dt) = args
+                j.src, j.dst, j.start = src.value, dst.value, total
+                total += j.rows_p * j.Kp
+                jobs.append(j)
+            else:
+                rest.append((fn, args))
+        if not jobs:
+            return
+        arr = (_lib.PackJob * len(jobs))(*jobs)
+        raw = bytes(arr)
+        self._pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+        n, tot = len(jobs), total
+
+        def pack_all():
+            _lib.check(L.y5m_pack_weights_batched(_lib.ptr(self._pack_table), n, tot, dt, _lib.stream_ptr()),
+                       "y5m_pack_weights_batched")
+        pack_all.kind = "pack_weights"
+        self.pack = [(pack_all, ())] + rest
 
     # ------------------------------------------------------------------ execution
     @staticmethod
