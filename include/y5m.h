@@ -147,6 +147,8 @@ typedef struct {
     int32_t Np;          /* stats row stride >= roundup(N, y5m_conv_tile_n(N))                   */
     int32_t naxs, nch;   /* HEAD                                                                 */
     int32_t tiles_m, tiles_n;   /* filled by the library                                         */
+    const void* zeros;   /* >= 16 zero bytes in device memory: padding / out-of-range chunks of a    */
+                         /* tile are LOADED from here, which keeps the tile loads branch-free        */
 } y5m_conv_args;
 
 int y5m_conv_tile_n(int N);   /* channel tile (48 or 96) the library uses for N output channels */
@@ -165,6 +167,7 @@ typedef struct {
     int32_t M, lddy, lddw;
     int32_t ksplit;      /* pixel-range splits (<=0: library picks)                              */
     int32_t tiles_n, tiles_c;   /* filled by the library                                         */
+    const void* zeros;   /* >= 16 zero bytes in device memory (see y5m_conv_args)                 */
 } y5m_wgrad_args;
 int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
 

@@ -33,14 +33,27 @@ class ConvArgs(ctypes.Structure):
                                       "osx", "ooy", "oox", "epi", "act", "accumulate")] +
                 [("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("ldres", c_int),
                  ("stats", c_void_p), ("Np", c_int), ("naxs", c_int), ("nch", c_int), ("tiles_m", c_int),
-                 ("tiles_n", c_int)])
+                 ("tiles_n", c_int), ("zeros", c_void_p)])
 
 
 class WgradArgs(ctypes.Structure):
     """mirror of y5m_wgrad_args (include/y5m.h)"""
     _fields_ = ([("dy", c_void_p), ("x", c_void_p), ("dwgt", c_void_p)] +
                 [(n, c_int) for n in ("B", "Hin", "Win", "ldx", "Hg", "Wg", "sy", "sx", "th", "tw", "dh0", "dhs",
-                                      "dw0", "dws", "C", "N", "M", "lddy", "lddw", "ksplit", "tiles_n", "tiles_c")])
+                                      "dw0", "dws", "C", "N", "M", "lddy", "lddw", "ksplit", "tiles_n", "tiles_c")] +
+                [("zeros", c_void_p)])
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    """64 zero bytes on `device` (the `zeros` field of y5m_conv_args / y5m_wgrad_args)."""
+    key = str(device)
+    t = _zero_pages.get(key)
+    if t is None:
+        t = _zero_pages[key] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return t
 
 
 class PackJob(ctypes.Structure):

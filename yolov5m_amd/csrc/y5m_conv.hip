@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
-template <typename T, int WM, int WN, int MF, int NF>
+// DB = true : two LDS buffers, one barrier per K step (long K: MFMA-bound layers)
+// DB = false: one LDS buffer, two barriers per K step, half the LDS -> more resident workgroups per CU
+//             (short K, e.g. 1x1 convs with C <= 384: latency/HBM-bound, TLP hides the load latency)
+template <typename T, int WM, int WN, int MF, int NF, bool DB>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams P) {
     constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -62,38 +65,44 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         const int r = r0 + 32 * i;
         wrow[i] = W + (size_t)(n0 + (r < BN ? r : 0)) * P.Kp + q * CH;
     }
-    uint4 ra[NA], rb[NB];
-    auto load_tile = [&](int kt) {
-        const int dh = P.dh0 + ta * P.dhs, dw = P.dw0 + tb * P.dws;
-        const bool kvalid = ta < P.th;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[NA], rb[NB];
+    // Loads are UNCONDITIONAL: out-of-range / padding chunks read the device zero page (address select
+    // before the load), so there are no exec-masked branches around the loads and no data-dependent
+    // fix-up after them: all NA+NB loads of a tile stay in flight under the MFMAs of the previous tile.
+    // (byte offset of the zero page relative to X: ONE base pointer + a selected 64-bit offset compiles
+    // to a v_cndmask pair and a plain global_load; selecting between two POINTERS made hipcc branch)
+    const ptrdiff_t zoff = reinterpret_cast<const T*>(P.zeros) - X;      // in elements (both 16-byte aligned)
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+        // K padding (ta >= th) is folded into the row offset: the bounds test then fails for every pixel,
+        // so there is ONE per-lane condition and no separate (uniform) code path for the padding tile
+        const int dh = ta < P.th ? P.dh0 + ta * P.dhs : (1 << 24), dw = P.dw0 + tb * P.dws;
+        const int doff = dh * P.Win + dw;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int iy = iy0[i] + dh, ix = ix0[i] + dw;
-            const bool v = kvalid && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            if (v) ra[i] = *reinterpret_cast<const uint4*>(X + (size_t)(p0[i] + dh * P.Win + dw) * P.ldin + c);
-            else ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            const bool v = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            const ptrdiff_t off = v ? (ptrdiff_t)((size_t)(p0[i] + doff) * P.ldin + c) : zoff;
+            ra[i] = *reinterpret_cast<const u32x4*>(X + off);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (r0 + 32 * i < BN) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kt * BK);
-            else rb[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt * BK);
     };
-    auto advance_k = [&]() {
+    auto advance_k = [&]() __attribute__((always_inline)) {
         c += BK;
         while (c >= P.Cin) {
             c -= P.Cin;
             if (++tb == P.tw) { tb = 0; ++ta; }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
         unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + lds_off(r0 + 32 * i, q)) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(As + lds_off(r0 + 32 * i, q)) = ra[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            if (r0 + 32 * i < BN) *reinterpret_cast<uint4*>(Bs + lds_off(r0 + 32 * i, q)) = rb[i];
+            if (r0 + 32 * i < BN) *reinterpret_cast<u32x4*>(Bs + lds_off(r0 + 32 * i, q)) = rb[i];
     };
 
     f32x4 acc[NF][MF];
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -138,14 +147,24 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     load_tile(0);
     store_tile(0);
     __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) { advance_k(); load_tile(kt + 1); }
-        compute(cur);
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    if constexpr (DB) {
+        int cur = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = kt + 1 < nkt;
+            if (more) { advance_k(); load_tile(kt + 1); }
+            compute(cur);
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = kt + 1 < nkt;
+            if (more) { advance_k(); load_tile(kt + 1); }
+            compute(0);
+            __syncthreads();
+            if (more) { store_tile(0); __syncthreads(); }
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
@@ -239,13 +258,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     }
 }
 
-template <typename T, int WM, int WN, int MF, int NF>
-static int launch_conv(ConvParams& P, hipStream_t st) {
+template <typename T, int WM, int WN, int MF, int NF, bool DB>
+static int launch_conv_db(ConvParams& P, hipStream_t st) {
     constexpr int BN = WN * NF * 16;
     P.tiles_m = (P.M + CV_BM - 1) / CV_BM;
     P.tiles_n = (P.N + BN - 1) / BN;
-    const size_t lds = 2 * (size_t)(CV_BM + BN) * 128;
-    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF>;
+    const size_t lds = (DB ? 2 : 1) * (size_t)(CV_BM + BN) * 128;
+    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, DB>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -259,6 +278,15 @@ static int launch_conv(ConvParams& P, hipStream_t st) {
 // Channel tile: 48 for the 48-channel layers, 192 (wave tile 64x96: half the LDS bytes per MFMA of the
 // 96 tile) when N is a multiple of 192, else 96. Y5M_CONV_BN192=0 disables the wide tile (A/B runs).
 static int g_bn192 = -1;
+static int g_sbuf_kt = -1;   // K steps up to which the single-buffer variant is used (Y5M_CONV_SBUF_KT, default 6)
+template <typename T, int WM, int WN, int MF, int NF>
+static int launch_conv(ConvParams& P, hipStream_t st) {
+    if (g_sbuf_kt < 0) { const char* e = getenv("Y5M_CONV_SBUF_KT"); g_sbuf_kt = e ? atoi(e) : 6; }
+    const int BK = sizeof(T) == 2 ? 64 : 32;
+    if (P.Kp / BK <= g_sbuf_kt) return launch_conv_db<T, WM, WN, MF, NF, false>(P, st);
+    return launch_conv_db<T, WM, WN, MF, NF, true>(P, st);
+}
+
 extern "C" int y5m_conv_tile_n(int N) {
     if (g_bn192 < 0) { const char* e = getenv("Y5M_CONV_BN192"); g_bn192 = (e && e[0] == '0') ? 0 : 1; }
     if (N <= 48) return 48;
@@ -272,6 +300,7 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     memcpy(&P, args, sizeof(P));
     const int CH = dtype == Y5M_BF16 ? 8 : 4, BK = dtype == Y5M_BF16 ? 64 : 32;
     Y5M_REQUIRE(dtype == Y5M_F32 || dtype == Y5M_BF16, "dtype");
+    Y5M_REQUIRE(P.zeros != nullptr, "args.zeros (16 zero bytes in device memory) is required");
     Y5M_REQUIRE(P.Cin % CH == 0 && P.ldin % CH == 0, "Cin/ldin must be multiples of the 16-byte chunk");
     Y5M_REQUIRE(P.Kp % BK == 0 && P.Kp >= P.K && P.K == P.th * P.tw * P.Cin, "K padding");
     Y5M_REQUIRE(P.M == P.B * P.Hg * P.Wg && P.M > 0, "M");

@@ -9,6 +9,7 @@
 // Block tile 96(n) x 96(c), 2x2 waves of 48x48, one tap and one pixel range (split-K) per block; the
 // f32 partial tiles are combined with atomicAdd into the packed f32 gradient (coalesced along c).
 #include "y5m_conv.h"
+#include <stdlib.h>
 
 #define WG_THREADS 256
 #define WG_TN 96
@@ -30,7 +31,7 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* sub, int lane, i
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 
-template <typename T>
+template <typename T, bool DB>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) {
     constexpr int KCH = WgTraits<T>::KCH;
     constexpr int OPB = WgTraits<T>::OPB;            // bytes of one operand tile
@@ -72,29 +73,32 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
         pl[i] = (id >> 2) % KCH;
         ccl[i] = ((id >> 2) / KCH) * 4 + (id & 3);
     }
-    uint4 ry[NLD], rx[NLD];
-    auto load_chunk = [&](int chunk) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ry[NLD], rx[NLD];
+    // unconditional loads: padding / out-of-range chunks come from the device zero page
+    const char* Yb = reinterpret_cast<const char*>(DY);
+    const char* Xb = reinterpret_cast<const char*>(X);
+    const ptrdiff_t zy = reinterpret_cast<const char*>(P.zeros) - Yb, zx = reinterpret_cast<const char*>(P.zeros) - Xb;
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int m = chunk * KCH + pl[i];
             const int ch = ccl[i] * CH;
-            ry[i] = make_uint4(0u, 0u, 0u, 0u);
-            rx[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (m < P.M) {
-                if (n0 + ch < P.N) ry[i] = *reinterpret_cast<const uint4*>(DY + (size_t)m * P.lddy + n0 + ch);
-                if (c0 + ch < P.C) {
-                    const int gx = m % P.Wg;
-                    const int t = m / P.Wg;
-                    const int gy = t % P.Hg;
-                    const int b = t / P.Hg;
-                    const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
-                    if ((unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win)
-                        rx[i] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * P.Hin + iy) * P.Win + ix) * P.ldx + c0 + ch);
-                }
-            }
+            const bool mv = m < P.M;
+            const bool yv = mv && (n0 + ch < P.N);
+            const int gx = m % P.Wg;
+            const int t = m / P.Wg;
+            const int gy = t % P.Hg;
+            const int b = t / P.Hg;
+            const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
+            const bool xv = mv && (c0 + ch < P.C) && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            const ptrdiff_t yo = yv ? (ptrdiff_t)(((size_t)m * P.lddy + n0 + ch) * sizeof(T)) : zy;
+            const ptrdiff_t xo = xv ? (ptrdiff_t)((((size_t)(b * P.Hin + iy) * P.Win + ix) * P.ldx + c0 + ch) * sizeof(T)) : zx;
+            ry[i] = *reinterpret_cast<const u32x4*>(Yb + yo);
+            rx[i] = *reinterpret_cast<const u32x4*>(Xb + xo);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
         unsigned char* Ys = smem + buf * 2 * OPB;
         unsigned char* Xs = Ys + OPB;
 #pragma unroll
@@ -106,8 +110,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
             } else {
                 off = (pl[i] * WgTraits<float>::LDW + ccl[i] * 4) * 4;
             }
-            *reinterpret_cast<uint4*>(Ys + off) = ry[i];
-            *reinterpret_cast<uint4*>(Xs + off) = rx[i];
+            *reinterpret_cast<u32x4*>(Ys + off) = ry[i];
+            *reinterpret_cast<u32x4*>(Xs + off) = rx[i];
         }
     };
 
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* Ys = smem + buf * 2 * OPB;
         const unsigned char* Xs = Ys + OPB;
         if constexpr (sizeof(T) == 2) {
@@ -168,14 +172,24 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
         load_chunk(ch_lo);
         store_chunk(0);
         __syncthreads();
-        int cur = 0;
-        for (int chk = ch_lo; chk < ch_hi; ++chk) {
-            const bool more = chk + 1 < ch_hi;
-            if (more) load_chunk(chk + 1);
-            compute(cur);
-            if (more) store_chunk(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+        if constexpr (DB) {
+            int cur = 0;
+            for (int chk = ch_lo; chk < ch_hi; ++chk) {
+                const bool more = chk + 1 < ch_hi;
+                if (more) load_chunk(chk + 1);
+                compute(cur);
+                if (more) store_chunk(cur ^ 1);
+                __syncthreads();
+                cur ^= 1;
+            }
+        } else {
+            for (int chk = ch_lo; chk < ch_hi; ++chk) {
+                const bool more = chk + 1 < ch_hi;
+                if (more) load_chunk(chk + 1);
+                compute(0);
+                __syncthreads();
+                if (more) { store_chunk(0); __syncthreads(); }
+            }
         }
         // D[n][c]: lane owns n = (lane>>4)*4 + r, c = lane&15 -> atomics coalesced along c
         const int i = lane & 15, g = lane >> 4;
@@ -198,6 +212,7 @@ extern "C" int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream) {
     WgradParams P = *args;
     const int CH = dtype == Y5M_BF16 ? 8 : 4;
     Y5M_REQUIRE(dtype == Y5M_F32 || dtype == Y5M_BF16, "dtype");
+    Y5M_REQUIRE(P.zeros != nullptr, "args.zeros (16 zero bytes in device memory) is required");
     Y5M_REQUIRE(P.C % CH == 0 && P.N % CH == 0 && P.ldx % CH == 0 && P.lddy % CH == 0, "channel counts must be multiples of 16 bytes");
     Y5M_REQUIRE(P.M == P.B * P.Hg * P.Wg && P.M > 0, "M");
     P.tiles_n = (P.N + WG_TN - 1) / WG_TN;
@@ -214,18 +229,21 @@ extern "C" int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream) {
         ks = ks > maxks ? maxks : ks;
         P.ksplit = ks < 1 ? 1 : ks;
     }
-    const size_t lds = 4 * (size_t)(dtype == Y5M_BF16 ? WgTraits<bf16_t>::OPB : WgTraits<float>::OPB);
+    static int sbuf = -1;      // Y5M_WGRAD_SBUF=1: single LDS buffer (half the LDS, more resident workgroups)
+    if (sbuf < 0) { const char* e = getenv("Y5M_WGRAD_SBUF"); sbuf = (e && e[0] == '1') ? 1 : 0; }
+    const size_t opb = (size_t)(dtype == Y5M_BF16 ? WgTraits<bf16_t>::OPB : WgTraits<float>::OPB);
+    const size_t lds = (sbuf ? 2 : 4) * opb;
     const unsigned grid = (unsigned)(P.tiles_n * P.tiles_c * taps * P.ksplit);
     hipStream_t st = y5m_stream(stream);
-    if (dtype == Y5M_BF16) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(WG_THREADS), lds, st, P);
-    } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(WG_THREADS), lds, st, P);
+#define WG_LAUNCH(TT, DBV)                                                                                   \
+    {                                                                                                        \
+        static bool attr = false;                                                                            \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_kernel<TT, DBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+        hipLaunchKernelGGL((wgrad_kernel<TT, DBV>), dim3(grid), dim3(WG_THREADS), lds, st, P);               \
     }
+    if (dtype == Y5M_BF16) { if (sbuf) WG_LAUNCH(bf16_t, false) else WG_LAUNCH(bf16_t, true) }
+    else { if (sbuf) WG_LAUNCH(float, false) else WG_LAUNCH(float, true) }
+#undef WG_LAUNCH
     Y5M_CHECK_LAUNCH("wgrad_kernel");
     return Y5M_OK;
 }

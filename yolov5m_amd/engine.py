@@ -111,6 +111,7 @@ class Engine:
     # ------------------------------------------------------------------ conv descriptors
     def _conv_args(self, x, w, out_ptr, Ho, Wo, k, s, p, N, ldout, epi, Kp, cin=None, **kw):
         a = ConvArgs()
+        a.zeros = _lib.zero_page(self.dev).data_ptr()
         cin = cin if cin is not None else x.C
         a.inp, a.w, a.out = x.ptr, w.data_ptr(), out_ptr
         a.B, a.Hin, a.Win, a.ldin = x.B, x.H, x.W, x.ld
@@ -255,6 +256,7 @@ class Engine:
                              self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ()))
             # weight gradient (packed f32, atomics into the zeroed gw buffer)
             wa = WgradArgs()
+            wa.zeros = _lib.zero_page(self.dev).data_ptr()
             wa.dy, wa.x = self.scratch.data_ptr(), lay.x.ptr
             wa.dwgt = self.gw.data_ptr() + 4 * lay.gw_off
             wa.B, wa.Hin, wa.Win, wa.ldx = lay.x.B, lay.x.H, lay.x.W, lay.x.ld
@@ -282,6 +284,7 @@ class Engine:
                 for (wd, py, px, tht, kh0, khs, dh0, kw0, kws, dw0) in lay.wd:
                     th, tw = (tht, tht) if isinstance(tht, int) else tht
                     a = ConvArgs()
+                    a.zeros = _lib.zero_page(self.dev).data_ptr()
                     a.inp, a.w, a.out = dyA.ptr, wd.data_ptr(), xg.ptr
                     a.B, a.Hin, a.Win, a.ldin = dyA.B, dyA.H, dyA.W, dyA.ld
                     if lay.ss == 1:
@@ -392,6 +395,7 @@ class Engine:
                     L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(self.scratch),
                                          ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack"), ()))
                 wa = WgradArgs()
+                wa.zeros = _lib.zero_page(self.dev).data_ptr()
                 wa.dy, wa.x, wa.dwgt = self.scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
                 wa.B, wa.Hin, wa.Win, wa.ldx = x.B, x.H, x.W, x.ld
                 wa.Hg, wa.Wg, wa.sy, wa.sx = x.H, x.W, 1, 1
@@ -406,6 +410,7 @@ class Engine:
                 acc = 1 if x.gw else 0
                 x.gw = True
                 a = ConvArgs()
+                a.zeros = _lib.zero_page(self.dev).data_ptr()
                 a.inp, a.w, a.out = self.scratch.data_ptr(), wd.data_ptr(), x.grad.ptr
                 a.B, a.Hin, a.Win, a.ldin = x.B, x.H, x.W, ldp
                 a.Hg, a.Wg, a.sy, a.sx = x.H, x.W, 1, 1

@@ -54,6 +54,7 @@ def conv_forward(x, w, stride, pad, dtype="f32", scale=None, shift=None, act=Fal
     wf, Kp, Np = pack_fwd(w, dtype)
     out = torch.zeros((B, Ho, Wo, Cout), dtype=tdt, device=x.device)
     a = ConvArgs()
+    a.zeros = _lib.zero_page(x.device).data_ptr()
     a.inp, a.w, a.out = xn.data_ptr(), wf.data_ptr(), out.data_ptr()
     a.B, a.Hin, a.Win, a.ldin = B, H, W, Cin
     a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
@@ -92,6 +93,7 @@ def conv_forward_stats(x, w, stride, pad, dtype="f32"):
     tiles_m = (M + 127) // 128
     stats = torch.zeros((tiles_m, 2, Np), dtype=torch.float32, device=x.device)
     a = ConvArgs()
+    a.zeros = _lib.zero_page(x.device).data_ptr()
     a.inp, a.w, a.out = xn.data_ptr(), wf.data_ptr(), out.data_ptr()
     a.B, a.Hin, a.Win, a.ldin = B, H, W, Cin
     a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
@@ -129,6 +131,7 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32"):
         _lib.check(L.y5m_pack_weights(_lib.ptr(wsrc), Cout, Cin, k, k, 1, kh0, khs, th, kw0, kws, tw, _lib.ptr(wd),
                                       wd.shape[0], wd.shape[1], 0, dt, _lib.stream_ptr()), "y5m_pack_weights")
         a = ConvArgs()
+        a.zeros = _lib.zero_page(dy.device).data_ptr()
         a.inp, a.w, a.out = dyn.data_ptr(), wd.data_ptr(), dx.data_ptr()
         a.B, a.Hin, a.Win, a.ldin = B, Ho, Wo, Cout
         if stride == 1:
@@ -154,6 +157,7 @@ def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0):
     dyn, xn = to_nhwc(dy, tdt), to_nhwc(x, tdt)
     gp = torch.zeros((Cout, k * k * Cin), dtype=torch.float32, device=dy.device)
     a = WgradArgs()
+    a.zeros = _lib.zero_page(dy.device).data_ptr()
     a.dy, a.x, a.dwgt = dyn.data_ptr(), xn.data_ptr(), gp.data_ptr()
     a.B, a.Hin, a.Win, a.ldx = B, H, W, Cin
     a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
