@@ -90,6 +90,7 @@ class Engine:
         self.nc, self.naxs = model.head.nc, model.head.naxs
         self.nch = 5 + self.nc
         self.fwd, self.bwd = [], []
+        self._pending = {}
         self._bwd_stack = []
         self.layers = []
         self._scratch_elems = 0
@@ -241,6 +242,9 @@ class Engine:
             z = lay.z
             dz = z.grad
             bn = lay.bn
+            slot = self._next_slot()
+            scratch = self.scratch2[slot]
+            ops.append((self._join_op(slot), ()))     # previous user of this dy buffer (its wgrad) must be done
             # residual branch: d(res) (+)= dz   (Bottleneck add, model.py:50)
             if lay.res is not None and lay.res.grad is not None:
                 acc = 1 if lay.res.gw else 0
@@ -252,25 +256,27 @@ class Engine:
             ops.append((lambda: _lib.check(
                 L.y5m_bn_bwd(dz.ptr, dz.ld, _lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
                              bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]),
-                             _lib.ptr(P["gb"]), 0, _lib.ptr(self.scratch), lay.cout, _lib.ptr(self.bnws),
+                             _lib.ptr(P["gb"]), 0, _lib.ptr(scratch), lay.cout, _lib.ptr(self.bnws),
                              self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ()))
             # weight gradient (packed f32, atomics into the zeroed gw buffer)
             wa = WgradArgs()
             wa.zeros = _lib.zero_page(self.dev).data_ptr()
-            wa.dy, wa.x = self.scratch.data_ptr(), lay.x.ptr
+            wa.dy, wa.x = scratch.data_ptr(), lay.x.ptr
             wa.dwgt = self.gw.data_ptr() + 4 * lay.gw_off
             wa.B, wa.Hin, wa.Win, wa.ldx = lay.x.B, lay.x.H, lay.x.W, lay.x.ld
             wa.Hg, wa.Wg, wa.sy, wa.sx = lay.Ho, lay.Wo, lay.ss, lay.ss
             wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = lay.kk, lay.kk, -lay.pp, 1, -lay.pp, 1
             wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = lay.x.C, lay.cout, lay.M, lay.cout, lay.ldgw, 0
             lay.wgrad_args = wa
-            ops.append((_kind(lambda wa=wa: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad"), "wgrad"), ()))
-            # packed f32 -> reference-layout flat gradient, right away: the layer's slice of the flat
-            # gradient buffer is then final, which is what lets the all-reduce start bucket by bucket
+            # weight gradient + its unpack (packed f32 -> reference-layout flat gradient) run on the SIDE
+            # stream, concurrently with this layer's data gradient and the next layer's BN backward:
+            # wgrad is HBM/atomic-bound, dgrad MFMA-bound, and neither fills the chip alone
             mode = 2 if lay.stem else 0
-            ops.append((lambda: _lib.check(
+            f_wg = lambda wa=wa: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad")
+            f_up = lambda: _lib.check(
                 L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, lay.cout, lay.cin_real, lay.k, lay.k, mode,
-                                   lay.ldgw, _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad"), ()))
+                                   lay.ldgw, _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad")
+            ops.append((self._side_op([f_wg, f_up], slot), ()))
             self._grad_done.append((lay.name, P["gw"].data_ptr()))
             # data gradient
             if need_dx:
@@ -280,7 +286,7 @@ class Engine:
                 for c in lay.x.children:
                     c.gw = True
                 lay.dgrad_args = []
-                dyA = Act(self.scratch, lay.x.B, lay.Ho, lay.Wo, lay.cout)
+                dyA = Act(scratch, lay.x.B, lay.Ho, lay.Wo, lay.cout)
                 for (wd, py, px, tht, kh0, khs, dh0, kw0, kws, dw0) in lay.wd:
                     th, tw = (tht, tht) if isinstance(tht, int) else tht
                     a = ConvArgs()
@@ -391,27 +397,31 @@ class Engine:
 
             def backward(lay=lay, x=x, P=P, wd=wd, ldp=ldp, M=M, N=N):
                 ops = []
+                slot = self._next_slot()
+                scratch = self.scratch2[slot]
+                ops.append((self._join_op(slot), ()))
                 ops.append((lambda: _lib.check(
-                    L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(self.scratch),
+                    L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch),
                                          ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack"), ()))
                 wa = WgradArgs()
                 wa.zeros = _lib.zero_page(self.dev).data_ptr()
-                wa.dy, wa.x, wa.dwgt = self.scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
+                wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
                 wa.B, wa.Hin, wa.Win, wa.ldx = x.B, x.H, x.W, x.ld
                 wa.Hg, wa.Wg, wa.sy, wa.sx = x.H, x.W, 1, 1
                 wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
                 wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = x.C, ldp, M, ldp, x.C, 0
                 lay.wgrad_args = wa
-                ops.append((_kind(lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(head)"), "wgrad"), ()))
-                ops.append((lambda: _lib.check(
+                f_wg = lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(head)")
+                f_up = lambda: _lib.check(
                     L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, N, x.C, 1, 1, 0, lay.ldgw,
-                                       _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(head)"), ()))
+                                       _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(head)")
+                ops.append((self._side_op([f_wg, f_up], slot), ()))
                 self._grad_done.append((lay.name, P["gw"].data_ptr()))
                 acc = 1 if x.gw else 0
                 x.gw = True
                 a = ConvArgs()
                 a.zeros = _lib.zero_page(self.dev).data_ptr()
-                a.inp, a.w, a.out = self.scratch.data_ptr(), wd.data_ptr(), x.grad.ptr
+                a.inp, a.w, a.out = scratch.data_ptr(), wd.data_ptr(), x.grad.ptr
                 a.B, a.Hin, a.Win, a.ldin = x.B, x.H, x.W, ldp
                 a.Hg, a.Wg, a.sy, a.sx = x.H, x.W, 1, 1
                 a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = 1, 1, 0, -1, 0, -1
@@ -477,7 +487,8 @@ class Engine:
         for a in self._stat_users:
             a.stats = self.stats.data_ptr()
         if self.training:
-            self.scratch = torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev)
+            self.scratch2 = [torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev) for _ in range(2)]
+            self.scratch = self.scratch2[0]
             self.bnws = torch.zeros((self._bnws_bytes,), dtype=torch.uint8, device=self.dev)
             self.gw = torch.zeros((self._gw_floats,), dtype=torch.float32, device=self.dev)
             # expand the backward stack in reverse order; plan-time gradient-written flags
@@ -490,6 +501,52 @@ class Engine:
                 self.bwd.extend(mk())
                 for name, addr in self._grad_done[n0:]:
                     self.bwd_marks.append((len(self.bwd), name, addr))
+            self.bwd.append((self._join_op(0), ()))
+            self.bwd.append((self._join_op(1), ()))
+
+    # ------------------------------------------------------------------ side-stream overlap (backward)
+    def _next_slot(self):
+        self._slot_seq = getattr(self, "_slot_seq", -1) + 1
+        return self._slot_seq & 1
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def _side_op(self, fns, slot):
+        """Run `fns` on the side stream, ordered after everything enqueued so far on the current stream
+        (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
+        hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
+        import os
+        overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"
+
+        def run():
+            if not overlap:
+                for f in fns:
+                    f()
+                return
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for f in fns:
+                    f()
+                done = torch.cuda.Event()
+                done.record(side)
+            self._pending[slot] = done
+        run.kind = "wgrad"
+        return run
+
+    def _join_op(self, slot):
+        def run():
+            ev = self._pending.pop(slot, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+        run.kind = "join"
+        return run
 
     def _batch_packs(self):
         """Fold every y5m_pack_weights entry of self.pack into ONE launch over a device job table."""
