@@ -62,8 +62,8 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
     uint2 q;
-    q.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    q.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    q.x = f32x2_to_bf16x2(v[0], v[1]);
+    q.y = f32x2_to_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = q;
 }
 

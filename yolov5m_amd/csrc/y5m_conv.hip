@@ -35,10 +35,17 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     // ---- per-thread staging state ------------------------------------------------------------
     const int q = tid & 7, r0 = tid >> 3;
     int p0[NA], iy0[NA], ix0[NA];
+    // pointwise fast path (1x1, stride 1, no padding, same grid): input pixel == output pixel index,
+    // no (b, y, x) decomposition (two integer divisions per row) needed
+    const bool lin_in = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 &&
+                        P.Hin == P.Hg && P.Win == P.Wg;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + 32 * i;
-        if (m < P.M) {
+        if (lin_in) {
+            p0[i] = m; ix0[i] = 0;
+            iy0[i] = m < P.M ? 0 : -(1 << 28);
+        } else if (m < P.M) {
             const int gx = m % P.Wg;
             const int t = m / P.Wg;
             const int gy = t % P.Hg;
@@ -205,15 +212,22 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         }
     }
 
+    // dense output (no strided scatter): output pixel index == m, skip the decomposition
+    const bool lin_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
+                         P.Hout == P.Hg && P.Wout == P.Wg;
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
         const int m = mb + b * 16;
         if (m >= P.M) continue;
-        const int gx = m % P.Wg;
-        const int t = m / P.Wg;
-        const int gy = t % P.Hg;
-        const int bi = t / P.Hg;
-        const size_t opix = ((size_t)bi * P.Hout + (gy * P.osy + P.ooy)) * P.Wout + (gx * P.osx + P.oox);
+        int gx = 0, gy = 0, bi = 0;
+        size_t opix = (size_t)m;
+        if (!lin_out) {
+            gx = m % P.Wg;
+            const int t = m / P.Wg;
+            gy = t % P.Hg;
+            bi = t / P.Hg;
+            opix = ((size_t)bi * P.Hout + (gy * P.osy + P.ooy)) * P.Wout + (gx * P.osx + P.oox);
+        }
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
             const int n = nb + a * 16;

@@ -91,6 +91,8 @@ class Engine:
         self.nch = 5 + self.nc
         self.fwd, self.bwd = [], []
         self._pending = {}
+        import os
+        self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
         self._bwd_stack = []
         self.layers = []
         self._scratch_elems = 0
@@ -518,11 +520,8 @@ class Engine:
         """Run `fns` on the side stream, ordered after everything enqueued so far on the current stream
         (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
         hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
-        import os
-        overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"
-
         def run():
-            if not overlap:
+            if not self.overlap:
                 for f in fns:
                     f()
                 return

@@ -189,9 +189,13 @@ class NativeTrainStep:
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
         tl = []
-        self._enqueue_fb(eng, tl)
-        self._optimizer(tl)
-        torch.cuda.synchronize()
+        saved, eng.overlap = eng.overlap, False      # serialise the side stream so per-family times add up
+        try:
+            self._enqueue_fb(eng, tl)
+            self._optimizer(tl)
+            torch.cuda.synchronize()
+        finally:
+            eng.overlap = saved
         fam = {}
         for kind, e0, e1 in tl:
             ms, n = fam.get(kind, (0.0, 0))
