@@ -65,6 +65,48 @@ def cpu_baseline(B=4, size=640, steps=2):
                       f"({os.cpu_count()} logical CPUs)"}
 
 
+def detect_leg(dev, B=128, size=1280, iters=5):
+    """configs[4]: decode + per-image NMS on B x N candidate boxes (N = 100 800 at 1280^2), synthetic
+    logits regime (ii) of SURVEY 8d: obj-logit ~ N(-5, 2^2), box/cls logits ~ N(0,1), seed 0.
+    boxes/sec = B*N candidates consumed by decode + threshold + NMS per second (inputs resident in HBM)."""
+    from yolov5m_amd import config
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    from yolov5m_amd.utils.bboxes_utils import nms_batched
+    g = torch.Generator(device=dev).manual_seed(0)
+    logits = []
+    for s_ in (8, 16, 32):
+        ny = nx = size // s_
+        t = torch.randn((B, 3, ny, nx, 85), generator=g, device=dev, dtype=torch.float32)
+        t[..., 4] = t[..., 4] * 2.0 - 5.0
+        logits.append(t)
+    anchors = (torch.tensor(config.ANCHORS).float().view(3, -1, 2) / torch.tensor([8., 16., 32.]).view(3, 1, 1)).to(dev)
+    N = sum(t.shape[1] * t.shape[2] * t.shape[3] for t in logits)
+    out = {}
+    for name, (thr, iou) in {"detect.py (0.25, 0.45)": (0.25, 0.45), "eval (0.01, 0.6)": (0.01, 0.6)}.items():
+        for _ in range(2):
+            boxes = cells_to_bboxes(logits, anchors, [8, 16, 32], is_pred=True, to_list=False)
+            rows, idx, cnt = nms_batched(boxes, iou, thr, 300)
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        td = tn = 0.0
+        for _ in range(iters):
+            e0.record()
+            boxes = cells_to_bboxes(logits, anchors, [8, 16, 32], is_pred=True, to_list=False)
+            e1.record()
+            rows, idx, cnt = nms_batched(boxes, iou, thr, 300)
+            e2.record()
+            torch.cuda.synchronize()
+            td += e0.elapsed_time(e1)
+            tn += e1.elapsed_time(e2)
+        td, tn = td / iters, tn / iters
+        cand = int((boxes[..., 1] > thr).sum())
+        out[name] = {"boxes_per_sec": round(B * N / ((td + tn) * 1e-3)), "decode_ms": round(td, 3), "nms_ms": round(tn, 3),
+                     "candidates_per_image": round(cand / B, 1), "kept_per_image": round(float(cnt.float().mean()), 1),
+                     "decode_GBps": round(B * N * (85 * 4 + 24) / (td * 1e-3) / 1e9, 1)}
+    return {"workload": f"decode + NMS, batch {B} @ {size}x{size} ({N} candidate boxes/image), synthetic logits "
+                        f"(obj ~ N(-5,2^2)), max_detections 300 (BASELINE.json configs[4])", "unit": "boxes/s", **out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +118,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-detect", action="store_true")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -166,6 +209,11 @@ def main():
             "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
             "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
         }
+    if world == 1 and not args.no_detect:
+        del step, images
+        model._engines = {}
+        torch.cuda.empty_cache()
+        out["detect"] = detect_leg(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

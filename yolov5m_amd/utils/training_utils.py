@@ -170,12 +170,21 @@ class NativeTrainStep:
                 self.grad_hook(self.model.flat_grads)
             self._optimizer()
             torch.cuda.synchronize()
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._enqueue_fb(eng)
-            with torch.cuda.graph(g2):
-                self._optimizer()
-            self._graph, self._key = (g1, g2), key
+            try:
+                # thread_local: a RCCL watchdog / other thread touching the HIP runtime must not abort the capture
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    self._enqueue_fb(eng)
+                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                    self._optimizer()
+                self._graph, self._key = (g1, g2), key
+            except Exception as e:                       # capture is an optimisation, never a requirement
+                import warnings
+                warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
+                torch.cuda.synchronize()
+                self.use_graph = False
+                eng._pending.clear()
+                return self.loss_out
         g1, g2 = self._graph
         g1.replay()
         if self.grad_hook is not None:
