@@ -112,6 +112,17 @@ int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int n
                      const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
                      float* loss_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Replaces YOLO_LOSS.compute_loss for all 3 scales (loss.py:195-246, summed as in :93-97) and its
+ * autograd backward. dense[i] (B,naxs,ny_i,nx_i,6) = [x,y,w,h,obj,cls] targets as built by
+ * YOLO_LOSS.build_targets (loss.py:101-192): obj==1 positives, obj==-1 "ignore" cells whose BCE target
+ * stays -1 (reference behaviour, loss.py:220). rows_max >= number of positives per scale.
+ * loss_out[4] as y5m_compute_loss; NaN when a scale has no positives (loss.py:212). */
+size_t y5m_compute_loss_dense_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int rows_max);
+int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
+                           int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
+                           const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                           float* loss_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Model (model.py): Conv-BN-SiLU building blocks. Activations are (ptr, ld) NHWC, dtype per call.
  * ------------------------------------------------------------------------------------------- */

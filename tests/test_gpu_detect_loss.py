@@ -245,3 +245,50 @@ def test_compute_loss_b64_vs_oracle(anchors):
         ref = pc[i].grad.numpy()
         got = pg[i].grad.cpu().numpy()
         assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9
+
+
+# ---------------------------------------------------------------------------------------------- YOLO_LOSS
+def test_yolo_loss_golden_pinned_sequence(golden, anchors):
+    """reference loss.py on a FRESH object with a pinned call sequence (anchor decay state)"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    g = golden("g4_yolo_loss")
+    B = int(g["B"])
+    lf = YOLO_LOSS(_StubModel(anchors), rect_training=False)
+    # dense targets of the first image of a fresh object: exact
+    fresh = YOLO_LOSS(_StubModel(anchors), rect_training=False)
+    shapes = [tuple(s) for s in g["shapes"]]
+    p0 = [torch.zeros(1, 3, ny, nx, 85, device=DEV) for (ny, nx) in shapes]
+    tg = fresh.build_targets(p0, g["0/boxes0"], (64, 64))
+    for i in range(3):
+        assert np.array_equal(tg[i].numpy(), g[f"bt/t{i}"])
+    for call in range(2):
+        assert np.array_equal(lf.anchors.numpy(), g[f"{call}/anchors_before"])
+        p = [torch.from_numpy(g[f"{call}/p{i}"]).to(DEV).requires_grad_(True) for i in range(3)]
+        boxes = tuple(g[f"{call}/boxes{b}"] for b in range(B))
+        loss = lf(p, boxes, pred_size=(64, 64))
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(g[f"{call}/loss"]), rtol=1e-4)
+        assert np.array_equal(lf.anchors.numpy(), g[f"{call}/anchors_after"])
+        for i in range(3):
+            ref = g[f"{call}/g{i}"]
+            got = p[i].grad.cpu().numpy()
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, (call, i)
+
+
+def test_yolo_loss_single_scale_and_nan(anchors):
+    from yolov5m_amd.loss import YOLO_LOSS
+    from oracle.loss_ref import YoloLossRef
+    lf = YOLO_LOSS(_StubModel(anchors), rect_training=False)
+    ref = YoloLossRef(anchors)
+    shapes = [(8, 8), (4, 4), (2, 2)]
+    boxes = (np.array([[3, 0.5, 0.5, 0.3, 0.4], [7, 0.2, 0.7, 0.1, 0.2]]), np.array([[1, 0.6, 0.4, 0.5, 0.5]]))
+    p = [uniform(f"yl/{i}", (2, 3, ny, nx, 85), -3.0, 3.0) for i, (ny, nx) in enumerate(shapes)]
+    tg = [ref.build_targets(shapes, b) for b in boxes]
+    for i in range(3):
+        dense = torch.stack([t[i] for t in tg], 0)
+        lr = ref.compute_loss(p[i].clone(), dense.clone(), ref.anchors_d[i], loss_ref.BALANCE[i])
+        lg, logs = lf.compute_loss(p[i].to(DEV), dense.clone().to(DEV), lf.anchors_d[i], lf.balance[i])
+        np.testing.assert_allclose(float(lg), float(lr), rtol=1e-4)
+    # no boxes at all -> NaN, as the reference (loss.py:212)
+    l = lf([t.to(DEV) for t in p], (np.zeros((0, 5)), np.zeros((0, 5))), pred_size=(64, 64))
+    assert bool(torch.isnan(l))

@@ -11,8 +11,9 @@ CPU fallback: ops raise Y5MError on CPU tensors or when the library is missing.
 from . import _lib, config  # noqa: F401
 from .model import YOLOV5m  # noqa: F401
 from .ultralytics_loss import ComputeLoss  # noqa: F401
+from .loss import YOLO_LOSS  # noqa: F401
 from .utils.plot_utils import cells_to_bboxes, make_grids  # noqa: F401
 from .utils.bboxes_utils import non_max_suppression, intersection_over_union, iou_width_height  # noqa: F401
 
-__all__ = ["YOLOV5m", "ComputeLoss", "cells_to_bboxes", "make_grids", "non_max_suppression",
+__all__ = ["YOLOV5m", "ComputeLoss", "YOLO_LOSS", "cells_to_bboxes", "make_grids", "non_max_suppression",
            "intersection_over_union", "iou_width_height", "config"]

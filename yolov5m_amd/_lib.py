@@ -89,6 +89,10 @@ _SIGS = {
     "y5m_compute_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                  c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
+    "y5m_compute_loss_dense_workspace_bytes": (c_size_t, [c_int, c_int, c_void_p, c_void_p, c_int]),
+    "y5m_compute_loss_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "y5m_conv_tile_n": (c_int, [c_int]),
     "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),

@@ -164,11 +164,13 @@ struct LossScale {
     int ny, nx, cap, nblk;
     int64_t cells;
     float balance;
+    const float* dense;    // YOLO_LOSS mode: dense targets (B,naxs,ny,nx,6); objectness target = channel 4
 };
 struct LossArgs {
     LossScale s[3];
     int B, naxs, nc, nch;
     float lam_box, lam_obj, lam_cls;
+    int dense_mode;        // 1: reference loss.py semantics (ignore cells keep target -1, empty mean = NaN)
 };
 
 __device__ __forceinline__ float bce_logits(float x, float t) {   // BCEWithLogits, pos_weight = 1
@@ -179,6 +181,7 @@ __device__ __forceinline__ float bce_logits(float x, float t) {   // BCEWithLogi
 template <bool BWD>
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs A) {
     const LossScale& S = A.s[blockIdx.y];
+    if (!S.p) return;                                  // absent scale (single-scale YOLO_LOSS.compute_loss)
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = *S.count;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A) {
     __shared__ float red[4];
     __shared__ float gsm[4][64];
     const LossScale& S = A.s[blockIdx.y];
-    if ((int)blockIdx.x >= S.nblk) return;
+    if (!S.p || (int)blockIdx.x >= S.nblk) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t c0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
     const int64_t cell = c0 + lane;
@@ -249,7 +252,11 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A) {
     if (cell < S.cells) {
         const float x = S.p[cell * A.nch + 4];
         const int ow = S.owner[cell];
-        const float t = ow >= 0 ? S.rowiou[ow] : 0.0f;
+        float t = ow >= 0 ? S.rowiou[ow] : 0.0f;
+        if (S.dense) {                                   // loss.py:217-220: obj cells *= giou, -1 (ignore) stays -1
+            const float d = S.dense[cell * 6 + 4];
+            t = d == 1.0f ? t : d;
+        }
         bce = bce_logits(x, t);                                          // :101
         gobj = (sigmoidf_(x) - t) * (S.balance * A.lam_obj * (float)A.B / (float)S.cells);
     }
@@ -309,10 +316,14 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(LossArgs A, float* 
     float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
     for (int s = 0; s < 3; ++s) {
         const LossScale& S = A.s[s];
+        if (!S.p) continue;
         const int n = *S.count;
         if (n > 0) {
             lbox += block_sum_f(S.rowlbox, n, sm) / (float)n;                    // :85 mean
             if (A.nc > 1) lcls += block_sum_f(S.rowcls, n, sm) / ((float)n * (float)A.nc);   // :95
+        } else if (A.dense_mode) {                       // loss.py:212,231: mean over an empty selection is NaN
+            lbox += __int_as_float(0x7fc00000);
+            lcls += __int_as_float(0x7fc00000);
         }
         lobj += (block_sum_f(S.objpart, S.nblk, sm) / (float)S.cells) * S.balance;            // :101-102
     }
@@ -343,21 +354,22 @@ extern "C" size_t y5m_compute_loss_workspace_bytes(int B, int naxs, const int* n
     return loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
 }
 
-extern "C" int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int naxs, const int* ny,
-                                const int* nx, int nc, const y5m_targets tg[3], int nt_max,
-                                const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
-                                float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+static int run_loss(const float* const p[3], float* const grad[3], const float* const dense[3], int B, int naxs,
+                    const int* ny, const int* nx, int nc, const y5m_targets tg[3], int nt_max, const float balance[3],
+                    float lambda_box, float lambda_obj, float lambda_cls, float* loss_out, void* ws, size_t ws_bytes,
+                    hipStream_t st) {
     Y5M_REQUIRE(B >= 1 && naxs >= 1 && nc >= 1, "bad dims");
     Y5M_REQUIRE(5 + nc <= 128, "5+nc must be <= 128 (one wave holds a logit row in two registers)");
     size_t off[3][5]; int nblk[3];
     const size_t need = loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
     if (ws_bytes < need) { y5m_set_error("compute_loss ws too small"); return Y5M_EWS; }
-    hipStream_t st = y5m_stream(stream);
     char* w = reinterpret_cast<char*>(ws);
     LossArgs A;
     A.B = B; A.naxs = naxs; A.nc = nc; A.nch = 5 + nc;
     A.lam_box = lambda_box; A.lam_obj = lambda_obj; A.lam_cls = lambda_cls;
-    const bool want_grad = grad && grad[0] && grad[1] && grad[2];
+    A.dense_mode = dense ? 1 : 0;
+    bool want_grad = grad != nullptr;
+    for (int s = 0; s < 3; ++s) if (p[s] && !(grad && grad[s])) want_grad = false;
     int max_blk = 0;
     const int cap = 5 * naxs * (nt_max > 0 ? nt_max : 1);
     for (int s = 0; s < 3; ++s) {
@@ -372,6 +384,8 @@ extern "C" int y5m_compute_loss(const float* const p[3], float* const grad[3], i
         S.ny = ny[s]; S.nx = nx[s]; S.cap = cap; S.nblk = nblk[s];
         S.cells = (int64_t)B * naxs * ny[s] * nx[s];
         S.balance = balance[s];
+        S.dense = dense ? dense[s] : nullptr;
+        if (!S.p) { S.nblk = 0; S.cells = 0; continue; }
         max_blk = nblk[s] > max_blk ? nblk[s] : max_blk;
         if (hipMemsetAsync(S.owner, 0xFF, (size_t)S.cells * 4, st) != hipSuccess) { y5m_set_error("memset owner"); return Y5M_ELAUNCH; }
     }
@@ -390,4 +404,89 @@ extern "C" int y5m_compute_loss(const float* const p[3], float* const grad[3], i
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, A, loss_out);
     Y5M_CHECK_LAUNCH("loss_finalize_kernel");
     return Y5M_OK;
+}
+
+extern "C" int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int naxs, const int* ny,
+                                const int* nx, int nc, const y5m_targets tg[3], int nt_max,
+                                const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    return run_loss(p, grad, nullptr, B, naxs, ny, nx, nc, tg, nt_max, balance, lambda_box, lambda_obj, lambda_cls,
+                    loss_out, ws, ws_bytes, y5m_stream(stream));
+}
+
+// =================================================================================================
+// YOLO_LOSS.compute_loss (reference loss.py:195-246) on dense targets (B,naxs,ny,nx,6)
+// =================================================================================================
+// positives (targets[...,4] == 1) -> row table in row-major cell order (= boolean-mask order of :198-204)
+__global__ __launch_bounds__(BT_T) void dense_to_rows_kernel(const float* d0, const float* d1, const float* d2,
+                                                            const float* __restrict__ anchors, int B, int naxs,
+                                                            int ny0, int ny1, int ny2, int nx0, int nx1, int nx2,
+                                                            int cap, BtOut out) {
+    __shared__ int wave_tot[BT_T / 64];
+    const int s = blockIdx.x;
+    const float* d = s == 0 ? d0 : (s == 1 ? d1 : d2);
+    const int ny = s == 0 ? ny0 : (s == 1 ? ny1 : ny2);
+    const int nx = s == 0 ? nx0 : (s == 1 ? nx1 : nx2);
+    const int64_t cells = (int64_t)B * naxs * ny * nx;
+    if (!d) { if (threadIdx.x == 0) *out.count[s] = 0; return; }
+    int n = 0;
+    for (int64_t c0 = 0; c0 < cells; c0 += BT_T) {
+        const int64_t c = c0 + threadIdx.x;
+        const bool pos = c < cells && d[c * 6 + 4] == 1.0f;
+        int total;
+        const int rank = block_rank(pos, wave_tot, total);
+        if (pos && n + rank < cap) {
+            const int row = n + rank;
+            const int gi = (int)(c % nx);
+            int64_t t = c / nx;
+            const int gj = (int)(t % ny);
+            t /= ny;
+            const int a = (int)(t % naxs);
+            const int b = (int)(t / naxs);
+            reinterpret_cast<int4*>(out.bagg[s])[row] = make_int4(b, a, gj, gi);
+            reinterpret_cast<float4*>(out.tbox[s])[row] = make_float4(d[c * 6 + 0], d[c * 6 + 1], d[c * 6 + 2], d[c * 6 + 3]);
+            reinterpret_cast<float2*>(out.anch[s])[row] = make_float2(anchors[(s * naxs + a) * 2], anchors[(s * naxs + a) * 2 + 1]);
+            out.tcls[s][row] = (int)d[c * 6 + 5];
+        }
+        n += total;
+    }
+    if (threadIdx.x == 0) *out.count[s] = n < cap ? n : cap;
+}
+
+static size_t dense_tables_bytes(int rows) {
+    const size_t r = (size_t)(rows > 0 ? rows : 1);
+    return 3 * (y5m_align(4) + y5m_align(r * 16) + y5m_align(r * 16) + y5m_align(r * 8) + y5m_align(r * 4));
+}
+static int dense_nt(int rows_max, int naxs) { return (rows_max + 5 * naxs - 1) / (5 * naxs) + 1; }
+
+extern "C" size_t y5m_compute_loss_dense_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int rows_max) {
+    size_t off[3][5]; int nblk[3];
+    return dense_tables_bytes(5 * naxs * dense_nt(rows_max, naxs)) + loss_ws_layout(B, naxs, ny, nx, dense_nt(rows_max, naxs), off, nblk) + 256;
+}
+
+extern "C" int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
+                                      int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
+                                      const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                      float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    if (ws_bytes < y5m_compute_loss_dense_workspace_bytes(B, naxs, ny, nx, rows_max)) { y5m_set_error("loss_dense ws too small"); return Y5M_EWS; }
+    hipStream_t st = y5m_stream(stream);
+    const int nt = dense_nt(rows_max, naxs);
+    const int cap = 5 * naxs * nt;
+    char* w = reinterpret_cast<char*>(ws);
+    y5m_targets tg[3];
+    BtOut o;
+    for (int s = 0; s < 3; ++s) {
+        tg[s].count = reinterpret_cast<int32_t*>(w); w += y5m_align(4);
+        tg[s].bagg = reinterpret_cast<int32_t*>(w); w += y5m_align((size_t)cap * 16);
+        tg[s].tbox = reinterpret_cast<float*>(w); w += y5m_align((size_t)cap * 16);
+        tg[s].anch = reinterpret_cast<float*>(w); w += y5m_align((size_t)cap * 8);
+        tg[s].tcls = reinterpret_cast<int32_t*>(w); w += y5m_align((size_t)cap * 4);
+        o.count[s] = tg[s].count; o.bagg[s] = tg[s].bagg; o.tbox[s] = tg[s].tbox; o.anch[s] = tg[s].anch; o.tcls[s] = tg[s].tcls;
+    }
+    hipLaunchKernelGGL(dense_to_rows_kernel, dim3(3), dim3(BT_T), 0, st, dense[0], dense[1], dense[2], anchors, B, naxs,
+                       ny[0], ny[1], ny[2], nx[0], nx[1], nx[2], cap, o);
+    Y5M_CHECK_LAUNCH("dense_to_rows_kernel");
+    const size_t used = (size_t)(w - reinterpret_cast<char*>(ws));
+    return run_loss(p, grad, dense, B, naxs, ny, nx, nc, tg, nt, balance, lambda_box, lambda_obj, lambda_cls, loss_out, w,
+                    ws_bytes - used, st);
 }
