@@ -37,6 +37,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     int p0[NA], iy0[NA], ix0[NA];
     // pointwise fast path (1x1, stride 1, no padding, same grid): input pixel == output pixel index,
     // no (b, y, x) decomposition (two integer divisions per row) needed
+    const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
     const bool lin_in = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 &&
                         P.Hin == P.Hg && P.Win == P.Wg;
 #pragma unroll
@@ -46,10 +47,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
             p0[i] = m; ix0[i] = 0;
             iy0[i] = m < P.M ? 0 : -(1 << 28);
         } else if (m < P.M) {
-            const int gx = m % P.Wg;
-            const int t = m / P.Wg;
-            const int gy = t % P.Hg;
-            const int b = t / P.Hg;
+            int gx, t, gy, b;
+            fast_divmod(m, P.Wg, rcpW, t, gx);
+            fast_divmod(t, P.Hg, rcpH, b, gy);
             iy0[i] = gy * P.sy;
             ix0[i] = gx * P.sx;
             p0[i] = (b * P.Hin + iy0[i]) * P.Win + ix0[i];
@@ -222,10 +222,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         int gx = 0, gy = 0, bi = 0;
         size_t opix = (size_t)m;
         if (!lin_out) {
-            gx = m % P.Wg;
-            const int t = m / P.Wg;
-            gy = t % P.Hg;
-            bi = t / P.Hg;
+            int t;
+            fast_divmod(m, P.Wg, rcpW, t, gx);
+            fast_divmod(t, P.Hg, rcpH, bi, gy);
             opix = ((size_t)bi * P.Hout + (gy * P.osy + P.ooy)) * P.Wout + (gx * P.osx + P.oox);
         }
 #pragma unroll

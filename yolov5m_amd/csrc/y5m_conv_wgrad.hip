@@ -101,6 +101,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
     const char* Yb = reinterpret_cast<const char*>(DY);
     const char* Xb = reinterpret_cast<const char*>(X);
     const ptrdiff_t zy = reinterpret_cast<const char*>(P.zeros) - Yb, zx = reinterpret_cast<const char*>(P.zeros) - Xb;
+    const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+    // pointwise layers: X pixel == dY pixel, no (b, y, x) decomposition at all
+    const bool lin = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 && P.Hin == P.Hg &&
+                     P.Win == P.Wg;
     // unconditional loads: padding / out-of-range chunks come from the zero page (see y5m_conv.hip)
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
@@ -121,14 +125,17 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
             chunk_pc<KCH>(id, XCPR, pl, cc);
             const int m = chunk * KCH + pl;
             const int ch = cc * CH;
-            const int gx = m % P.Wg;
-            const int t = m / P.Wg;
-            const int gy = t % P.Hg;
-            const int b = t / P.Hg;
-            const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
-            const bool xv = id < C::NXC && m < P.M && (c0 + ch < P.C) && (unsigned)iy < (unsigned)P.Hin &&
-                            (unsigned)ix < (unsigned)P.Win;
-            const ptrdiff_t xo = xv ? (ptrdiff_t)((((size_t)(b * P.Hin + iy) * P.Win + ix) * P.ldx + c0 + ch) * sizeof(T)) : zx;
+            bool xv = id < C::NXC && m < P.M && (c0 + ch < P.C);
+            size_t pix = (size_t)m;
+            if (!lin) {
+                int gx, t, gy, b;
+                fast_divmod(m, P.Wg, rcpW, t, gx);
+                fast_divmod(t, P.Hg, rcpH, b, gy);
+                const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
+                xv = xv && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                pix = (size_t)(b * P.Hin + iy) * P.Win + ix;
+            }
+            const ptrdiff_t xo = xv ? (ptrdiff_t)((pix * P.ldx + c0 + ch) * sizeof(T)) : zx;
             rx[i] = *reinterpret_cast<const u32x4*>(Xb + xo);
         }
     };
