@@ -23,9 +23,11 @@ typedef y5m_wgrad_args WgradParams;
 // Each lane supplies the address of ITS OWN 8-byte piece of the 4x16 block its 16-lane group covers:
 // row (i>>2), columns 4*(i&3)..+3; the hardware returns column i, rows 0..3 (transposed).
 // (semantics verified on hardware: tools/probe_tr16.hip)
-__device__ __forceinline__ s16x4_t tr_read(const unsigned char* sub, int lane, int rowblk) {
-    const int i = lane & 15, g = lane >> 4;
-    const unsigned char* p = sub + ((rowblk * 16 + 4 * g + (i >> 2)) * 32 + (i & 3) * 8);
+// lane_off = (4*(lane>>4) + ((lane&15)>>2))*32 + (lane&3)*8 is loop invariant and computed once per thread.
+#define WG_SUB 1088     // sub-tile stride: 1024 + 64 so the 16-byte staging writes of neighbouring sub-tiles
+                        // and pixels fall on distinct LDS banks (a plain 1024 stride is a 2-way write conflict)
+__device__ __forceinline__ s16x4_t tr_read(const unsigned char* sub, int lane_off, int rowblk) {
+    const unsigned char* p = sub + lane_off + rowblk * 512;
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 
@@ -38,30 +40,19 @@ struct WgCfg {
     static constexpr int CH = BF ? 8 : 4;              // elements per 16-byte chunk
     static constexpr int LDY = BF ? TN : TN + 16;      // f32 row strides (+16: rows k, k+1 on disjoint banks)
     static constexpr int LDX = BF ? TC : TC + 16;
-    static constexpr int YB = KCH * LDY * (int)sizeof(T);   // bytes of the dY tile
-    static constexpr int XB = KCH * LDX * (int)sizeof(T);
-    static constexpr int NYC = KCH * (TN / CH);        // 16-byte chunks in the dY tile
-    static constexpr int NXC = KCH * (TC / CH);
-    static constexpr int NLDY = (NYC + WG_THREADS - 1) / WG_THREADS;
-    static constexpr int NLDX = (NXC + WG_THREADS - 1) / WG_THREADS;
+    static constexpr int YB = BF ? (KCH / 32) * (TN / 16) * WG_SUB : KCH * LDY * 4;   // bytes of the dY tile
+    static constexpr int XB = BF ? (KCH / 32) * (TC / 16) * WG_SUB : KCH * LDX * 4;
+    static constexpr int TPP = WG_THREADS / KCH;       // threads per pixel row of a chunk
+    static constexpr int YCPR = TN / CH, XCPR = TC / CH;   // 16-byte chunks per pixel row
+    static constexpr int NLDY = (YCPR + TPP - 1) / TPP;
+    static constexpr int NLDX = (XCPR + TPP - 1) / TPP;
 };
-
-// chunk id -> (pixel, chunk-in-row): groups of up to 4 consecutive chunks (64-byte runs) stay
-// together, pixels vary next
-template <int KCH>
-__device__ __forceinline__ void chunk_pc(int id, int cpr, int& pix, int& cc) {
-    const int g = cpr % 4 == 0 ? 4 : (cpr % 3 == 0 ? 3 : (cpr % 2 == 0 ? 2 : 1));   // must divide cpr
-    const int sub = id % g;
-    const int r = id / g;
-    pix = r % KCH;
-    cc = (r / KCH) * g + sub;
-}
 
 template <bool BF>
 __device__ __forceinline__ int lds_chunk_off(int pl, int cc, int tile_ch, int ldrow) {
     if constexpr (BF) {
         const int ch = cc * 8;
-        return ((pl >> 5) * (tile_ch / 16) + (ch >> 4)) * 1024 + (pl & 31) * 32 + ((ch >> 3) & 1) * 16;
+        return ((pl >> 5) * (tile_ch / 16) + (ch >> 4)) * WG_SUB + (pl & 31) * 32 + ((ch >> 3) & 1) * 16;
     } else {
         return (pl * ldrow + cc * 4) * 4;
     }
@@ -71,7 +62,6 @@ template <typename T, int WN, int WC, int WK, int CFR>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) {
     using C = WgCfg<T, WN, WC, WK, CFR>;
     constexpr int KCH = C::KCH, CH = C::CH;
-    constexpr int YCPR = C::TN / CH, XCPR = C::TC / CH;          // chunks per pixel row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -105,38 +95,37 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
     // pointwise layers: X pixel == dY pixel, no (b, y, x) decomposition at all
     const bool lin = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 && P.Hin == P.Hg &&
                      P.Win == P.Wg;
-    // unconditional loads: padding / out-of-range chunks come from the zero page (see y5m_conv.hip)
+    // Staging: thread = (pixel pl of the chunk, lane tp among the TPP threads of that pixel); it loads the
+    // 16-byte channel chunks tp, tp+TPP, ... of dY and of X for THAT pixel: one pixel decomposition per
+    // thread per chunk, TPP consecutive threads read a contiguous 16*TPP-byte run.
+    // Loads are unconditional: padding / out-of-range chunks come from the zero page (see y5m_conv.hip).
+    const int pl = tid / C::TPP, tp = tid % C::TPP;
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+        const int m = chunk * KCH + pl;
+        const bool mv = m < P.M;
+        bool xin = mv;
+        size_t pix = (size_t)m;
+        if (!lin) {
+            int gx, t, gy, b;
+            fast_divmod(m, P.Wg, rcpW, t, gx);
+            fast_divmod(t, P.Hg, rcpH, b, gy);
+            const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
+            xin = mv && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            pix = (size_t)(b * P.Hin + iy) * P.Win + ix;
+        }
+        const ptrdiff_t ybase = (ptrdiff_t)(((size_t)m * P.lddy + n0) * sizeof(T));
+        const ptrdiff_t xbase = (ptrdiff_t)((pix * P.ldx + c0) * sizeof(T));
 #pragma unroll
         for (int i = 0; i < C::NLDY; ++i) {
-            const int id = tid + WG_THREADS * i;
-            int pl, cc;
-            chunk_pc<KCH>(id, YCPR, pl, cc);
-            const int m = chunk * KCH + pl;
-            const int ch = cc * CH;
-            const bool yv = id < C::NYC && m < P.M && (n0 + ch < P.N);
-            const ptrdiff_t yo = yv ? (ptrdiff_t)(((size_t)m * P.lddy + n0 + ch) * sizeof(T)) : zy;
-            ry[i] = *reinterpret_cast<const u32x4*>(Yb + yo);
+            const int cc = tp + C::TPP * i;
+            const bool yv = mv && cc < C::YCPR && (n0 + cc * CH < P.N);
+            ry[i] = *reinterpret_cast<const u32x4*>(Yb + (yv ? ybase + cc * 16 : zy));
         }
 #pragma unroll
         for (int i = 0; i < C::NLDX; ++i) {
-            const int id = tid + WG_THREADS * i;
-            int pl, cc;
-            chunk_pc<KCH>(id, XCPR, pl, cc);
-            const int m = chunk * KCH + pl;
-            const int ch = cc * CH;
-            bool xv = id < C::NXC && m < P.M && (c0 + ch < P.C);
-            size_t pix = (size_t)m;
-            if (!lin) {
-                int gx, t, gy, b;
-                fast_divmod(m, P.Wg, rcpW, t, gx);
-                fast_divmod(t, P.Hg, rcpH, b, gy);
-                const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
-                xv = xv && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-                pix = (size_t)(b * P.Hin + iy) * P.Win + ix;
-            }
-            const ptrdiff_t xo = xv ? (ptrdiff_t)((pix * P.ldx + c0 + ch) * sizeof(T)) : zx;
-            rx[i] = *reinterpret_cast<const u32x4*>(Xb + xo);
+            const int cc = tp + C::TPP * i;
+            const bool xv = xin && cc < C::XCPR && (c0 + cc * CH < P.C);
+            rx[i] = *reinterpret_cast<const u32x4*>(Xb + (xv ? xbase + cc * 16 : zx));
         }
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
@@ -144,17 +133,13 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
         unsigned char* Xs = Ys + C::YB;
 #pragma unroll
         for (int i = 0; i < C::NLDY; ++i) {
-            const int id = tid + WG_THREADS * i;
-            int pl, cc;
-            chunk_pc<KCH>(id, YCPR, pl, cc);
-            if (id < C::NYC) *reinterpret_cast<u32x4*>(Ys + lds_chunk_off<C::BF>(pl, cc, C::TN, C::LDY)) = ry[i];
+            const int cc = tp + C::TPP * i;
+            if (cc < C::YCPR) *reinterpret_cast<u32x4*>(Ys + lds_chunk_off<C::BF>(pl, cc, C::TN, C::LDY)) = ry[i];
         }
 #pragma unroll
         for (int i = 0; i < C::NLDX; ++i) {
-            const int id = tid + WG_THREADS * i;
-            int pl, cc;
-            chunk_pc<KCH>(id, XCPR, pl, cc);
-            if (id < C::NXC) *reinterpret_cast<u32x4*>(Xs + lds_chunk_off<C::BF>(pl, cc, C::TC, C::LDX)) = rx[i];
+            const int cc = tp + C::TPP * i;
+            if (cc < C::XCPR) *reinterpret_cast<u32x4*>(Xs + lds_chunk_off<C::BF>(pl, cc, C::TC, C::LDX)) = rx[i];
         }
     };
 
@@ -169,20 +154,21 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
         const unsigned char* Xs = Ys + C::YB;
         if constexpr (C::BF) {
             constexpr int KS = KCH / 32 / WK;           // k-steps (32 pixels) of this wave per chunk
+            const int lane_off = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int ks = wk * KS + s;
                 uint4 ya[3], xb[CFR];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * 3 + a) * 1024;
-                    const s16x4_t lo = tr_read(sub, lane, 0), hi = tr_read(sub, lane, 1);
+                    const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * 3 + a) * WG_SUB;
+                    const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
                     ya[a] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
                 }
 #pragma unroll
                 for (int b = 0; b < CFR; ++b) {
-                    const unsigned char* sub = Xs + (ks * (C::TC / 16) + wc * CFR + b) * 1024;
-                    const s16x4_t lo = tr_read(sub, lane, 0), hi = tr_read(sub, lane, 1);
+                    const unsigned char* sub = Xs + (ks * (C::TC / 16) + wc * CFR + b) * WG_SUB;
+                    const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
                     xb[b] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
                 }
 #pragma unroll
@@ -253,9 +239,15 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     const int chunks = (P.M + C::KCH - 1) / C::KCH;
     if (P.ksplit <= 0) {
         // fill the chip (~4 blocks per CU) but keep >= 8 chunks per block so the prologue amortises
+        static int target = -1, minch = -1;     // Y5M_WGRAD_BLOCKS / Y5M_WGRAD_MINCH: tuning knobs
+        if (target < 0) { const char* e = getenv("Y5M_WGRAD_BLOCKS"); target = e ? atoi(e) : 0; }
+        if (minch < 0) { const char* e = getenv("Y5M_WGRAD_MINCH"); minch = e ? atoi(e) : 8; }
         const int base = P.tiles_n * P.tiles_c * taps;
-        int ks = (1024 + base - 1) / base;
-        const int maxks = (chunks + 7) / 8;
+        // measured (MI355X, B=64): every split adds one f32 atomic per output element, so pointwise layers
+        // (few, large output tiles) want ~1 block per CU, 3x3 layers ~4 per CU, the 48x16 stem tile more
+        const int tgt = target > 0 ? target : (taps == 1 ? 320 : (C::TC <= 16 ? 2048 : 1024));
+        int ks = (tgt + base - 1) / base;
+        const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
         P.ksplit = ks < 1 ? 1 : ks;
     }
