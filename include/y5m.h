@@ -234,8 +234,9 @@ int y5m_upsample2x(const void* in, int ldin, int B, int H, int W, int C, void* o
 int y5m_upsample2x_bwd(const void* gout, int ldg, int B, int H, int W, int C, void* gin, int ldgin,
                        int accumulate, int dtype, void* stream);
 /* SPPF (model.py:103-112): the three cascaded MaxPool2d(5,1,2) in one launch; backward per level */
-int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, int dtype,
-                  void* stream);
+size_t y5m_sppf_pool_workspace_bytes(int B, int H, int W, int C);
+int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, void* ws,
+                  size_t ws_bytes, int dtype, void* stream);
 size_t y5m_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C);
 int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
                      int ldgin, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -8,12 +8,91 @@
 // =================================================================================================
 // decode  (reference utils/plot_utils.py:10-54)
 // =================================================================================================
-#define DEC_THREADS 128
+#define DEC_THREADS 64
 #define DEC_WAVES (DEC_THREADS / 64)
 
 // One wave decodes 64 consecutive cells. The 64*(5+nc) logits of those cells are one contiguous
 // run in HBM: they are read with coalesced 16-byte loads into an LDS tile with an odd row stride,
 // then lane i walks the channels of cell i conflict-free.
+// Specialisation for a compile-time channel count (85 = 5 + 80 classes): a full 64-cell tile is
+// exactly NV = 64*NCH/4 float4 per wave; ALL of them are issued before the first LDS write (memory-level
+// parallelism), and every (cell, channel) position is a compile-time function of (iteration, lane).
+template <int NCH>
+__global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel_c(
+    const float* __restrict__ logits, int64_t cells, int naxs, int ny, int nx,
+    float aw0, float ah0, float aw1, float ah1, float aw2, float ah2, float stride,
+    float* __restrict__ out, int64_t N_total, int64_t row_offset) {
+    constexpr int LS = NCH | 1;
+    constexpr int NV = 64 * NCH / 4;            // float4 per full tile
+    constexpr int IT = (NV + 63) / 64;
+    __shared__ float tile[64 * LS];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int ncell = (int)((cells - c0) < 64 ? (cells - c0) : 64);
+    const float* src = logits + c0 * NCH;
+    if (ncell == 64) {
+        float4 q[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = lane + 64 * it;
+            q[it] = v < NV ? reinterpret_cast<const float4*>(src)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = lane + 64 * it;
+            if (v < NV) {
+                const int e = 4 * v;
+                int cell = e / NCH, ch = e - cell * NCH;
+                const float vals[4] = {q[it].x, q[it].y, q[it].z, q[it].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tile[cell * LS + ch] = vals[k];
+                    if (++ch == NCH) { ch = 0; ++cell; }
+                }
+            }
+        }
+    } else {
+        for (int e = lane; e < ncell * NCH; e += 64) {
+            const int cell = e / NCH, ch = e - cell * NCH;
+            tile[cell * LS + ch] = src[e];
+        }
+    }
+    __syncthreads();
+    if (lane >= ncell) return;
+    const float* row = tile + lane * LS;
+    const int64_t cell = c0 + lane;
+    const int gx = (int)(cell % nx);
+    int64_t t = cell / nx;
+    const int gy = (int)(t % ny);
+    t /= ny;
+    const int a = (int)(t % naxs);
+    const int64_t b = t / naxs;
+    const float sx = sigmoidf_(row[0]), sy = sigmoidf_(row[1]);
+    const float sw = sigmoidf_(row[2]), sh = sigmoidf_(row[3]);
+    const float obj = sigmoidf_(row[4]);
+    const float aw = a == 0 ? aw0 : (a == 1 ? aw1 : aw2);
+    const float ah = a == 0 ? ah0 : (a == 1 ? ah1 : ah2);
+    const float x = (2.0f * sx + (float)gx - 0.5f) * stride;
+    const float y = (2.0f * sy + (float)gy - 0.5f) * stride;
+    const float tw = 2.0f * sw, th = 2.0f * sh;
+    const float w = (tw * tw) * (aw * stride);
+    const float h = (th * th) * (ah * stride);
+    int best = 0;
+    float best_logit = row[5], best_sig = sigmoidf_(row[5]);
+#pragma unroll 4
+    for (int c = 1; c < NCH - 5; ++c) {
+        const float l = row[5 + c];
+        if (l > best_logit) {
+            const float s = sigmoidf_(l);
+            if (s > best_sig) { best_sig = s; best = c; best_logit = l; }
+        }
+    }
+    float* o = out + (b * N_total + row_offset + ((int64_t)a * ny + gy) * nx + gx) * 6;
+    reinterpret_cast<float2*>(o)[0] = make_float2((float)best, obj);
+    reinterpret_cast<float2*>(o)[1] = make_float2(x, y);
+    reinterpret_cast<float2*>(o)[2] = make_float2(w, h);
+}
+
 __global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel(
     const float* __restrict__ logits, int64_t cells, int naxs, int ny, int nx, int nch,
     float aw0, float ah0, float aw1, float ah1, float aw2, float ah2, float stride,
@@ -30,16 +109,21 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel(
     // coalesced fill: element e -> (cell = e / nch, ch = e % nch), tracked incrementally
     if (((uintptr_t)src & 15) == 0) {
         const int nvec = nelem >> 2;
+        // element e = 4*v -> (cell, ch); v advances by 64 per iteration = 256 elements = d256 cells + r256
+        // channels: tracked incrementally, no division in the loop
+        int cell0 = (4 * lane) / nch, ch0 = 4 * lane - cell0 * nch;
+        const int d256 = 256 / nch, r256 = 256 - d256 * nch;
         for (int v = lane; v < nvec; v += 64) {
             const float4 q = *reinterpret_cast<const float4*>(src + 4 * v);
-            int e = 4 * v;
-            int cell = e / nch, ch = e - cell * nch;
+            int cell = cell0, ch = ch0;
             const float vals[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 tile[cell * lstride + ch] = vals[k];
                 if (++ch == nch) { ch = 0; ++cell; }
             }
+            cell0 += d256; ch0 += r256;
+            if (ch0 >= nch) { ch0 -= nch; ++cell0; }
         }
         for (int e = (nvec << 2) + lane; e < nelem; e += 64) {
             int cell = e / nch, ch = e - cell * nch;
@@ -107,6 +191,13 @@ extern "C" int y5m_decode_scale(const float* logits, int B, int naxs, int ny, in
     }
     const int64_t blocks = (cells + DEC_THREADS - 1) / DEC_THREADS;
     const float* a = anchors_scale_host;
+    if (nch == 85 && (((uintptr_t)logits) & 15) == 0) {
+        hipLaunchKernelGGL(decode_pred_kernel_c<85>, dim3((unsigned)((cells + 63) / 64)), dim3(DEC_THREADS), 0,
+                           y5m_stream(stream), logits, cells, naxs, ny, nx, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
+                           N_total, row_offset);
+        Y5M_CHECK_LAUNCH("decode_pred_kernel_c<85>");
+        return Y5M_OK;
+    }
     hipLaunchKernelGGL(decode_pred_kernel, dim3((unsigned)blocks), dim3(DEC_THREADS), lds, y5m_stream(stream),
                        logits, cells, naxs, ny, nx, nch, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
                        N_total, row_offset);

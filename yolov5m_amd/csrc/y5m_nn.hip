@@ -569,40 +569,87 @@ extern "C" int y5m_upsample2x_bwd(const void* gout, int ldg, int B, int H, int W
 // SPPF pooling (reference model.py:103-112): three cascaded MaxPool2d(5,1,2) == windows 5, 9, 13 of x
 // (padding is -inf, so max-of-max composes exactly). One launch writes the 3 concat slices.
 // =================================================================================================
+// Separable: a horizontal pass builds the row maxima for windows 5 / 9 / 13, a vertical pass finishes
+// them; 8 channels (16 B) per thread and 13 + 27 vector loads per output instead of 169 scalar ones.
 template <typename T>
-__global__ void sppf_pool_kernel(const T* __restrict__ x, int ld, int B, int H, int W, int C, T* __restrict__ o1,
-                                 T* __restrict__ o2, T* __restrict__ o3) {
+__global__ void sppf_rowmax_kernel(const T* __restrict__ x, int ld, int B, int H, int W, int C8, T* __restrict__ h5,
+                                   T* __restrict__ h9, T* __restrict__ h13) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)B * H * W * C;
+    const int64_t n = (int64_t)B * H * W * C8;
     if (i >= n) return;
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    const int c = (int)(i % C8) * 8;
+    int64_t t = i / C8;
+    const int xx = (int)(t % W);
+    const int64_t row = t / W;               // b*H + y
+    float m5[8], m9[8], m13[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m5[k] = m9[k] = m13[k] = -INFINITY;
+    for (int dx = -6; dx <= 6; ++dx) {
+        const int x2 = xx + dx;
+        if (x2 < 0 || x2 >= W) continue;
+        float v[8];
+        load8<T>(x + (row * W + x2) * ld + c, v);
+        const int r = dx < 0 ? -dx : dx;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            m13[k] = fmaxf(m13[k], v[k]);
+            if (r <= 4) m9[k] = fmaxf(m9[k], v[k]);
+            if (r <= 2) m5[k] = fmaxf(m5[k], v[k]);
+        }
+    }
+    const size_t o = (size_t)(row * W + xx) * (C8 * 8) + c;
+    store8<T>(h5 + o, m5); store8<T>(h9 + o, m9); store8<T>(h13 + o, m13);
+}
+template <typename T>
+__global__ void sppf_colmax_kernel(const T* __restrict__ h5, const T* __restrict__ h9, const T* __restrict__ h13, int B,
+                                   int H, int W, int C8, T* __restrict__ o1, T* __restrict__ o2, T* __restrict__ o3, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * H * W * C8;
+    if (i >= n) return;
+    const int c = (int)(i % C8) * 8;
+    int64_t t = i / C8;
     const int xx = (int)(t % W); t /= W;
     const int yy = (int)(t % H);
     const int b = (int)(t / H);
-    float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
+    const int Cc = C8 * 8;
+    float m5[8], m9[8], m13[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m5[k] = m9[k] = m13[k] = -INFINITY;
     for (int dy = -6; dy <= 6; ++dy) {
         const int y2 = yy + dy;
         if (y2 < 0 || y2 >= H) continue;
-        for (int dx = -6; dx <= 6; ++dx) {
-            const int x2 = xx + dx;
-            if (x2 < 0 || x2 >= W) continue;
-            const float v = to_f32<T>(x[(((size_t)b * H + y2) * W + x2) * ld + c]);
-            const int r = max(abs(dy), abs(dx));
-            m13 = fmaxf(m13, v);
-            if (r <= 4) m9 = fmaxf(m9, v);
-            if (r <= 2) m5 = fmaxf(m5, v);
+        const size_t o = (((size_t)b * H + y2) * W + xx) * Cc + c;
+        const int r = dy < 0 ? -dy : dy;
+        float v[8];
+        load8<T>(h13 + o, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m13[k] = fmaxf(m13[k], v[k]);
+        if (r <= 4) {
+            load8<T>(h9 + o, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m9[k] = fmaxf(m9[k], v[k]);
+        }
+        if (r <= 2) {
+            load8<T>(h5 + o, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m5[k] = fmaxf(m5[k], v[k]);
         }
     }
     const size_t o = (((size_t)b * H + yy) * W + xx) * ld + c;
-    o1[o] = from_f32<T>(m5); o2[o] = from_f32<T>(m9); o3[o] = from_f32<T>(m13);
+    store8<T>(o1 + o, m5); store8<T>(o2 + o, m9); store8<T>(o3 + o, m13);
 }
-extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, int dtype,
-                             void* stream) {
-    const int64_t n = (int64_t)B * H * W * C;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(sppf_pool_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
-                                         (const T*)x, ld, B, H, W, C, (T*)o1, (T*)o2, (T*)o3);)
-    Y5M_CHECK_LAUNCH("sppf_pool_kernel");
+extern "C" size_t y5m_sppf_pool_workspace_bytes(int B, int H, int W, int C) { return (size_t)3 * B * H * W * C * 4 + 256; }
+extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, void* ws,
+                             size_t ws_bytes, int dtype, void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    if (ws_bytes < y5m_sppf_pool_workspace_bytes(B, H, W, C)) { y5m_set_error("sppf_pool ws too small"); return Y5M_EWS; }
+    const int64_t n = (int64_t)B * H * W * (C / 8);
+    const size_t plane = (size_t)B * H * W * C;
+    hipStream_t st = y5m_stream(stream);
+    DISPATCH_T(dtype, T* h5 = (T*)ws; T* h9 = h5 + plane; T* h13 = h9 + plane;
+               hipLaunchKernelGGL(sppf_rowmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)x, ld, B, H, W, C / 8, h5, h9, h13);
+               hipLaunchKernelGGL(sppf_colmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)h5, (const T*)h9, (const T*)h13, B, H, W, C / 8, (T*)o1, (T*)o2, (T*)o3, ld);)
+    Y5M_CHECK_LAUNCH("sppf_pool kernels");
     return Y5M_OK;
 }
 
@@ -610,74 +657,90 @@ extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, 
 // argmax = first maximum in (row, col) scan order, as ATen's max_pool2d_with_indices.
 // Pass 1 stores, per output, the window-relative position (0..24) of its argmax; pass 2 gathers.
 template <typename T>
-__global__ void maxpool5_argmax_kernel(const T* __restrict__ z, int ldz, int B, int H, int W, int C,
+__global__ void maxpool5_argmax_kernel(const T* __restrict__ z, int ldz, int B, int H, int W, int C8,
                                        unsigned char* __restrict__ code) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)B * H * W * C;
+    const int64_t n = (int64_t)B * H * W * C8;
     if (i >= n) return;
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    const int c = (int)(i % C8) * 8;
+    int64_t t = i / C8;
     const int ox = (int)(t % W); t /= W;
     const int oy = (int)(t % H);
     const int b = (int)(t / H);
-    const T* zb = z + (size_t)b * H * W * ldz + c;
-    float best = -INFINITY;
-    int bc = -1;
+    float best[8];
+    int bc[8];
 #pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bc[k] = -1; }
     for (int dy = 0; dy < 5; ++dy) {
         const int wy = oy + dy - 2;
         if (wy < 0 || wy >= H) continue;
-#pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
             const int wx = ox + dx - 2;
             if (wx < 0 || wx >= W) continue;
-            const float v = to_f32<T>(zb[((size_t)wy * W + wx) * ldz]);
-            if (v > best || bc < 0) { best = v; bc = dy * 5 + dx; }
+            float v[8];
+            load8<T>(z + (((size_t)b * H + wy) * W + wx) * ldz + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (v[k] > best[k] || bc[k] < 0) { best[k] = v[k]; bc[k] = dy * 5 + dx; }
         }
     }
-    code[i] = (unsigned char)bc;
+    uint2 pk;
+    pk.x = (unsigned)bc[0] | ((unsigned)bc[1] << 8) | ((unsigned)bc[2] << 16) | ((unsigned)bc[3] << 24);
+    pk.y = (unsigned)bc[4] | ((unsigned)bc[5] << 8) | ((unsigned)bc[6] << 16) | ((unsigned)bc[7] << 24);
+    *reinterpret_cast<uint2*>(code + ((((size_t)b * H + oy) * W + ox) * (C8 * 8) + c)) = pk;
 }
 template <typename T>
 __global__ void maxpool5_gather_kernel(const unsigned char* __restrict__ code, const T* __restrict__ g, int ldg, int B,
-                                       int H, int W, int C, T* __restrict__ gin, int ldgin, int accumulate) {
+                                       int H, int W, int C8, T* __restrict__ gin, int ldgin, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)B * H * W * C;
+    const int64_t n = (int64_t)B * H * W * C8;
     if (i >= n) return;
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    const int c = (int)(i % C8) * 8;
+    int64_t t = i / C8;
     const int xx = (int)(t % W); t /= W;
     const int yy = (int)(t % H);
     const int b = (int)(t / H);
-    float acc = 0.f;
-#pragma unroll
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int dy = -2; dy <= 2; ++dy) {
         const int oy = yy + dy;
         if (oy < 0 || oy >= H) continue;
-#pragma unroll
         for (int dx = -2; dx <= 2; ++dx) {
             const int ox = xx + dx;
             if (ox < 0 || ox >= W) continue;
             const size_t o = ((size_t)b * H + oy) * W + ox;
-            // (yy,xx) sits at window position (2-dy, 2-dx) of output (oy,ox)
-            if (code[o * C + c] == (unsigned char)((2 - dy) * 5 + (2 - dx))) acc += to_f32<T>(g[o * ldg + c]);
+            const uint2 pk = *reinterpret_cast<const uint2*>(code + o * (C8 * 8) + c);
+            const unsigned want = (unsigned)((2 - dy) * 5 + (2 - dx));   // (yy,xx) inside the window of (oy,ox)
+            float gv[8];
+            load8<T>(g + o * ldg + c, gv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned cd = ((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xffu;
+                if (cd == want) acc[k] += gv[k];
+            }
         }
     }
     T* d = gin + (((size_t)b * H + yy) * W + xx) * ldgin + c;
-    if (accumulate) acc += to_f32<T>(*d);
-    *d = from_f32<T>(acc);
+    if (accumulate) {
+        float o[8];
+        load8<T>(d, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += o[k];
+    }
+    store8<T>(d, acc);
 }
 extern "C" size_t y5m_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C) { return (size_t)B * H * W * C + 256; }
 extern "C" int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
                                 int ldgin, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    const int64_t n = (int64_t)B * H * W * C;
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    const int64_t n = (int64_t)B * H * W * (C / 8);
     if (ws_bytes < y5m_maxpool5_bwd_workspace_bytes(B, H, W, C)) { y5m_set_error("maxpool5_bwd ws too small"); return Y5M_EWS; }
     unsigned char* code = reinterpret_cast<unsigned char*>(ws);
     hipStream_t st = y5m_stream(stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_argmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)z, ldz, B,
-                                         H, W, C, code);)
+                                         H, W, C / 8, code);)
     Y5M_CHECK_LAUNCH("maxpool5_argmax_kernel");
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_gather_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, code, (const T*)g,
-                                         ldg, B, H, W, C, (T*)gin, ldgin, accumulate);)
+                                         ldg, B, H, W, C / 8, (T*)gin, ldgin, accumulate);)
     Y5M_CHECK_LAUNCH("maxpool5_gather_kernel");
     return Y5M_OK;
 }

@@ -335,8 +335,10 @@ class Engine:
         cat = self._new_act(x.B, x.H, x.W, 4 * c_)
         sl = [cat.slice(i * c_, c_) for i in range(4)]
         self._cbl(f"{name}.c1", x, c_, 1, 1, 0, dest=sl[0])
+        sppfws = torch.zeros((L.y5m_sppf_pool_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
         self.fwd.append((lambda: _lib.check(L.y5m_sppf_pool(sl[0].ptr, cat.ld, x.B, x.H, x.W, c_, sl[1].ptr, sl[2].ptr,
-                                                           sl[3].ptr, dt, st()), "y5m_sppf_pool"), ()))
+                                                           sl[3].ptr, _lib.ptr(sppfws), sppfws.numel(), dt, st()),
+                                            "y5m_sppf_pool"), ()))
         if self.training:
             poolws = torch.zeros((L.y5m_maxpool5_bwd_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
 
