@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liby5m.so")
+LIB_PATH = os.environ.get("Y5M_LIB") or os.path.join(_HERE, "liby5m.so")     # Y5M_LIB: experiment builds (tools/)
 
 c_void_p, c_int, c_int64, c_float, c_double, c_size_t = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t)

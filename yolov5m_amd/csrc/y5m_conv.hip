@@ -307,6 +307,8 @@ extern "C" int y5m_conv_tile_n(int N) {
     return 96;
 }
 
+int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st);      // y5m_conv_pw.hip
+
 extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     ConvParams P;
     static_assert(sizeof(P) == sizeof(*args), "abi struct");
@@ -322,6 +324,11 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     const int BN = y5m_conv_tile_n(P.N);
     Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
     hipStream_t st = y5m_stream(stream);
+    {
+        // short-K pointwise layers stream through the barrier-free kernel (y5m_conv_pw.hip)
+        const int r = y5m_conv_pw_try(P, dtype, st);
+        if (r != 0) return r < 0 ? r : Y5M_OK;
+    }
     if (dtype == Y5M_BF16) {
         if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
         if (BN == 192) return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);

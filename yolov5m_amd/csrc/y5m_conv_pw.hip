@@ -1,0 +1,249 @@
+// Pointwise (1x1, stride 1, dense in / dense out) convolution for short K (<= 192 input channels), bf16.
+//
+// Why a second kernel: the tiled implicit-GEMM kernel (y5m_conv.hip) spends 2-6 K steps per 128-pixel
+// tile on these layers, so its per-tile fixed work (staging through LDS, 2 barriers per K step, tile
+// prologue / epilogue) dominates: with ALL global traffic removed it only gets ~15 % faster, i.e. it is
+// neither HBM- nor MFMA-bound there. A pointwise conv is a streaming problem (read x once, write y once,
+// ~K flops per byte), so here:
+//   * the WEIGHTS of the workgroup's channel chunk (<= 96 channels x K) are staged into LDS once, already
+//     in MFMA A-fragment order (lane-linear 16 B per lane: every ds_read_b128 is conflict free);
+//   * every WAVE streams its own 16-pixel groups: x fragments go global -> VGPR directly in the MFMA B
+//     layout (lane = pixel l&15, 8 channels at (l>>4)*8 of a 32-channel K step), no LDS round trip and
+//     NO barrier in the streaming loop; the next group's loads are issued before the current group's MFMAs;
+//   * output channels are PERMUTED across the A rows so that a lane's 4*NCF accumulators are 4*NCF
+//     CONSECUTIVE channels of its pixel: D row rho = (l>>4)*4 + reg of fragment a holds channel
+//     n0 + (rho>>2)*(4*NCF) + a*4 + (rho&3)  ->  8*NCF contiguous bytes per lane, 32*NCF per pixel;
+//   * BatchNorm partial sums stay in registers for the whole stream and are reduced across the 16 pixel
+//     lanes and the 4 waves once at the end (one stats row per workgroup; unused rows are zeroed).
+#include "y5m_conv.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define PW_THREADS 256
+
+// NCF: 16-channel fragments per wave (3 -> 48-channel chunk, 6 -> 96); KS: 32-channel K steps.
+// OLD: the epilogue also reads a tensor of the output's shape (EPI_DGRAD: accumulate onto the existing
+// gradient; EPI_AFFINE_ACT: residual add).
+// The streaming loop has NO conditional memory instruction (M % 16 == 0 is a launch precondition and the
+// prefetch index is clamped instead of guarded): with every load / store on the straight path the compiler
+// can count them, so the wait for the prefetched x fragments is a vmcnt(#stores issued since) and the
+// output stores of group g drain under the MFMAs of group g+1 instead of being waited for.
+template <int NCF, int KS, int EPI, bool OLD>
+__global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams P, const int nchunks, const int nstreams,
+                                                               const int ngroups, const int stat_rows) {
+    constexpr int NC = NCF * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NCF][KS][64 lanes] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    // workgroup -> (stream block, channel chunk): the nchunks workgroups that re-read the same pixels run
+    // on the SAME XCD (hardware workgroup b is on XCD b % 8; gridDim.x is a multiple of 8 * nchunks)
+    const int b = blockIdx.x;
+    const int chunk = (b >> 3) % nchunks;
+    const int sblock = ((b >> 3) / nchunks) * 8 + (b & 7);
+    const int stream = sblock * 4 + wid;
+    const int n0 = chunk * NC;
+
+    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(P.in);
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(P.w);
+
+    // ---- weights -> LDS in A-fragment order (once) -------------------------------------------------
+    for (int f = wid; f < NCF * KS; f += PW_THREADS / 64) {
+        const int a = f / KS, s = f - a * KS;
+        const int ch = n0 + (fr >> 2) * (4 * NCF) + a * 4 + (fr & 3);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(W + (size_t)ch * P.Kp + s * 32 + fq * 8);
+        *reinterpret_cast<u32x4*>(smem + ((size_t)f * 64 + lane) * 16) = v;
+    }
+    __syncthreads();
+
+    const int cbase = n0 + fq * (4 * NCF);          // the lane's 4*NCF consecutive output channels
+    float sc[EPI == EPI_AFFINE_ACT ? 4 * NCF : 1], sh[EPI == EPI_AFFINE_ACT ? 4 * NCF : 1];
+    if constexpr (EPI == EPI_AFFINE_ACT) {
+#pragma unroll
+        for (int j = 0; j < 4 * NCF; ++j) { sc[j] = P.scale[cbase + j]; sh[j] = P.shift[cbase + j]; }
+    }
+    float ssum[EPI == EPI_RAW_STATS ? 4 * NCF : 1], ssq[EPI == EPI_RAW_STATS ? 4 * NCF : 1];
+    if constexpr (EPI == EPI_RAW_STATS) {
+#pragma unroll
+        for (int j = 0; j < 4 * NCF; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+    }
+
+    // ---- x fragment loads -----------------------------------------------------------------------------
+    const ptrdiff_t zoff = reinterpret_cast<const bf16_t*>(P.zeros) - X;
+    const bool klast_ok = (KS - 1) * 32 + fq * 8 < P.Cin;        // K % 32 == 16: upper half of the last step is padding
+    auto load_x = [&](u32x4 (&xr)[KS], int g) __attribute__((always_inline)) {
+        const size_t p = (size_t)g * 16 + fr;
+        const ptrdiff_t off = (ptrdiff_t)(p * P.ldin + fq * 8);
+#pragma unroll
+        for (int s = 0; s < KS - 1; ++s) xr[s] = *reinterpret_cast<const u32x4*>(X + off + s * 32);
+        ptrdiff_t last = off + (KS - 1) * 32;
+        asm("" : "+v"(last));
+        xr[KS - 1] = *reinterpret_cast<const u32x4*>(X + (klast_ok ? last : zoff));
+    };
+
+    // one 16-pixel group: x fragments in xr, prefetch of the stream's next group into xp
+    auto process = [&](const u32x4 (&xr)[KS], u32x4 (&xp)[KS], int g) __attribute__((always_inline)) {
+        const size_t p = (size_t)g * 16 + fr;
+        bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + p * P.ldout + cbase;
+        // read-modify-write / residual operand of THIS group first, then the next group's x fragments:
+        // the wait for `old` then leaves the prefetch in flight
+        u32x2 old[OLD ? NCF : 1];
+        if constexpr (OLD) {
+            const bf16_t* src = EPI == EPI_DGRAD ? o : reinterpret_cast<const bf16_t*>(P.res) + p * P.ldres + cbase;
+#pragma unroll
+            for (int a = 0; a < NCF; ++a) old[a] = *reinterpret_cast<const u32x2*>(src + a * 4);
+        }
+        {
+            const int gn = g + nstreams;
+            load_x(xp, gn < ngroups ? gn : g);      // clamped, not guarded (the last group is re-read once)
+        }
+        __builtin_amdgcn_sched_barrier(0);          // the prefetch is ISSUED before the MFMAs, not sunk below them
+
+        f32x4 acc[NCF];
+#pragma unroll
+        for (int a = 0; a < NCF; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int a = 0; a < NCF; ++a) {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(smem + ((size_t)(a * KS + s) * 64 + lane) * 16);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w),
+                                                                 __builtin_bit_cast(bf16x8_t, xr[s]), acc[a], 0, 0, 0);
+            }
+
+        // ---- epilogue: lane = pixel p, channels cbase + a*4 + r ------------------------------------
+#pragma unroll
+        for (int a = 0; a < NCF; ++a) {
+            float v[4] = {acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
+            if constexpr (EPI == EPI_RAW_STATS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[a * 4 + r] += v[r]; ssq[a * 4 + r] += v[r] * v[r]; }
+            }
+            if constexpr (EPI == EPI_AFFINE_ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = v[r] * sc[a * 4 + r] + sh[a * 4 + r];
+                    if (P.act == Y5M_ACT_SILU) v[r] = silu_f(v[r]);
+                }
+            }
+            if constexpr (OLD) {
+                v[0] += __uint_as_float(old[a].x << 16); v[1] += __uint_as_float(old[a].x & 0xffff0000u);
+                v[2] += __uint_as_float(old[a].y << 16); v[3] += __uint_as_float(old[a].y & 0xffff0000u);
+            }
+            u32x2 q;
+            q.x = f32x2_to_bf16x2(v[0], v[1]);
+            q.y = f32x2_to_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(o + a * 4) = q;
+        }
+    };
+
+    // ping-pong between two fragment sets (no register copies on the loop back edge)
+    u32x4 xa[KS], xb[KS];
+    int g = stream;
+    if (g < ngroups) {
+        load_x(xa, g);
+        for (;;) {
+            process(xa, xb, g);
+            g += nstreams;
+            if (g >= ngroups) break;
+            process(xb, xa, g);
+            g += nstreams;
+            if (g >= ngroups) break;
+        }
+    }
+
+    if constexpr (EPI == EPI_RAW_STATS) {
+        if (P.stats) {
+            // lanes -> wave (16 pixel lanes share a channel set), waves -> workgroup (through LDS, behind the
+            // weights), one stats row per WORKGROUP: row `sblock`; rows sblock + k*gridDim-per-chunk are zero
+            // padding so that the consumer (y5m_bn_finalize over stat_rows rows) needs no knowledge of the launch
+#pragma unroll
+            for (int j = 0; j < 4 * NCF; ++j) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, 64); ssq[j] += __shfl_xor(ssq[j], o, 64); }
+            }
+            float* red = reinterpret_cast<float*>(smem + (size_t)NCF * KS * 64 * 16);      // [4 waves][2][NC]
+            if (fr == 0) {
+#pragma unroll
+                for (int j = 0; j < 4 * NCF; ++j) {
+                    red[(wid * 2 + 0) * NC + fq * (4 * NCF) + j] = ssum[j];
+                    red[(wid * 2 + 1) * NC + fq * (4 * NCF) + j] = ssq[j];
+                }
+            }
+            __syncthreads();
+            const int nsb = nstreams >> 2;
+            for (int t = tid; t < 2 * NC; t += PW_THREADS) {
+                const int which = t / NC, c = t - which * NC;
+                const float v = red[(0 * 2 + which) * NC + c] + red[(1 * 2 + which) * NC + c] +
+                                red[(2 * 2 + which) * NC + c] + red[(3 * 2 + which) * NC + c];
+                for (int row = sblock, first = 1; row < stat_rows; row += nsb, first = 0)
+                    P.stats[((size_t)row * 2 + which) * P.Np + n0 + c] = first ? v : 0.f;
+            }
+        }
+    }
+}
+
+static int g_pw = -1;          // Y5M_CONV_PW=0 routes every layer through the tiled kernel (A/B runs)
+static int g_pw_occ = -1;      // Y5M_CONV_PW_OCC: workgroups per CU of the persistent grid
+
+template <int NCF, int KS, int EPI, bool OLD>
+static int launch_pw(const ConvParams& P, hipStream_t st) {
+    constexpr int NC = NCF * 16;
+    if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 2; }
+    const int nchunks = P.N / NC;
+    const int ngroups = (P.M + 15) / 16;
+    const int stat_rows = (P.M + CV_BM - 1) / CV_BM;                 // rows the caller sized the stats buffer for
+    // stream blocks (4 streams each): every CU gets g_pw_occ workgroups, in multiples of 8 per chunk (XCD mapping)
+    int sblocks = 256 * g_pw_occ / nchunks / 8 * 8;
+    if (sblocks < 8) sblocks = 8;
+    const int need = (ngroups + 3) / 4;
+    if (sblocks > (need + 7) / 8 * 8) sblocks = (need + 7) / 8 * 8;
+    if (EPI == EPI_RAW_STATS && P.stats && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
+    if (sblocks < 8) return 0;                                       // tiny problem: leave it to the tiled kernel
+    const int nstreams = sblocks * 4;
+    const size_t lds = (size_t)NCF * KS * 64 * 16 + (EPI == EPI_RAW_STATS ? 4 * 2 * NC * sizeof(float) : 0);
+    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(sblocks * nchunks)), dim3(PW_THREADS), lds, st, P, nchunks, nstreams, ngroups, stat_rows);
+    Y5M_CHECK_LAUNCH("conv_pw_kernel");
+    return 1;
+}
+
+template <int NCF, int KS>
+static int launch_pw_epi(const ConvParams& P, hipStream_t st) {
+    if (P.epi == EPI_RAW_STATS) return launch_pw<NCF, KS, EPI_RAW_STATS, false>(P, st);
+    if (P.epi == EPI_AFFINE_ACT)
+        return P.res ? launch_pw<NCF, KS, EPI_AFFINE_ACT, true>(P, st) : launch_pw<NCF, KS, EPI_AFFINE_ACT, false>(P, st);
+    return P.accumulate ? launch_pw<NCF, KS, EPI_DGRAD, true>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false>(P, st);
+}
+
+// Returns 1 when the launch was taken by the pointwise kernel, 0 when the layer does not qualify (the
+// caller then uses the tiled kernel), < 0 on error.
+int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
+    if (g_pw < 0) { const char* e = getenv("Y5M_CONV_PW"); g_pw = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_pw || dtype != Y5M_BF16) return 0;
+    const bool pointwise = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 &&
+                           P.Hin == P.Hg && P.Win == P.Wg;
+    const bool dense_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
+                           P.Hout == P.Hg && P.Wout == P.Wg;
+    if (!pointwise || !dense_out) return 0;
+    if (P.Cin % 16 != 0 || P.Cin > 192 || P.Cin <= 32 || P.N % 48 != 0 || P.M % 16 != 0) return 0;
+    if (P.epi == EPI_AFFINE_ACT && P.res && P.ldres % 4 != 0) return 0;
+    const int KS = (P.Cin + 31) / 32;
+    if (KS * 32 > P.Kp) return 0;
+    // channel chunk per workgroup: 96 when it divides N, else 48
+    if (P.N % 96 == 0) {
+        if (KS == 2) return launch_pw_epi<6, 2>(P, st);
+        if (KS == 3) return launch_pw_epi<6, 3>(P, st);
+        if (KS == 6) return launch_pw_epi<6, 6>(P, st);
+    } else {
+        if (KS == 2) return launch_pw_epi<3, 2>(P, st);
+        if (KS == 3) return launch_pw_epi<3, 3>(P, st);
+        if (KS == 6) return launch_pw_epi<3, 6>(P, st);
+    }
+    return 0;
+}
