@@ -6,10 +6,15 @@
 //   bf16: ds_read_b64_tr_b16 on [32 pixel][16 channel] sub-tiles (1 KiB each, the conflict-free
 //         layout of the CDNA4 guide) -> 4 pixels of one channel per lane per read, 2 reads per operand;
 //   f32 : plain ds_read_b32, lane (channel = lane&15, pixel = lane>>4) is exactly the 16x16x4 operand.
-// Block tile (WN*48)(n) x (WC*16*CFR)(c); the 4 waves are arranged WN x WC x WK: for the small-channel
+// Block tile (WN*16*NFR)(n) x (WC*16*CFR)(c), wave tile (16*NFR) x (16*CFR); the 4 waves are arranged WN x WC x WK: for the small-channel
 // layers (N or C <= 48, stem C = 16) the spare waves split the pixels of each chunk (WK) instead of
-// multiplying zero padding. One tap and one pixel range (split-K) per block; f32 partial tiles are
-// combined with atomicAdd into the packed f32 gradient (coalesced along c).
+// multiplying zero padding. One pixel range (split-K) per block; f32 partial tiles are combined with
+// atomicAdd into the packed f32 gradient (coalesced along c).
+// Taps: normally ONE tap per block (the 9 tap blocks of a pixel range run on one XCD and share dY through
+// its L2). For the small-C layers (stem C=16, the 48-channel stages) a block covers TPB taps at once: the X
+// tile is [pixel][TPB x CBLK "virtual channels"] (an im2col slice built by the loader, every 16-byte chunk
+// with its own tap offset and bounds test), so dY is read once per TPB taps and a wave gets 3 x 9 MFMAs per
+// 32-pixel step instead of 3 x 1 (stem) or 3 x 3.
 #include "y5m_conv.h"
 #include <stdlib.h>
 
@@ -31,10 +36,12 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* sub, int lane_of
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 
-template <typename T, int WN, int WC, int WK, int CFR>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR>
 struct WgCfg {
-    static constexpr int TN = WN * 48;                 // channels of dY per block
-    static constexpr int TC = WC * 16 * CFR;           // channels of X per block
+    static constexpr int TN = WN * 16 * NFR;                // channels of dY per block
+    static constexpr int TC = WC * 16 * CFR;           // (virtual) channels of X per block = TPB taps x CBLK
+    static constexpr int CBLK = TC / TPB;              // real channels per tap in the tile
+    static_assert(TC % TPB == 0 && CBLK % 16 == 0, "a 16-channel fragment must not straddle two taps");
     static constexpr bool BF = sizeof(T) == 2;
     static constexpr int KCH = BF ? 32 * (WK > 2 ? WK : 2) : 32;   // pixels per LDS chunk
     static constexpr int CH = BF ? 8 : 4;              // elements per 16-byte chunk
@@ -58,9 +65,9 @@ __device__ __forceinline__ int lds_chunk_off(int pl, int cc, int tile_ch, int ld
     }
 }
 
-template <typename T, int WN, int WC, int WK, int CFR>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR>
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) {
-    using C = WgCfg<T, WN, WC, WK, CFR>;
+    using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR>;
     constexpr int KCH = C::KCH, CH = C::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -72,13 +79,12 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
     const int nblk = gridDim.x, hb = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = hb & 7;
     int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hb >> 3);
-    const int tap = bid % (P.th * P.tw); bid /= (P.th * P.tw);
+    const int tgroups = (P.th * P.tw) / TPB;
+    const int tap0 = (bid % tgroups) * TPB; bid /= tgroups;
     const int ct = bid % P.tiles_c; bid /= P.tiles_c;
     const int nt = bid % P.tiles_n;
     const int ksp = bid / P.tiles_n;
-    const int n0 = nt * C::TN, c0 = ct * C::TC;
-    const int ta = tap / P.tw, tb = tap - ta * P.tw;
-    const int dh = P.dh0 + ta * P.dhs, dw = P.dw0 + tb * P.dws;
+    const int n0 = nt * C::TN, c0 = ct * C::CBLK;
 
     const T* __restrict__ DY = reinterpret_cast<const T*>(P.dy);
     const T* __restrict__ X = reinterpret_cast<const T*>(P.x);
@@ -88,45 +94,89 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
     const int ch_lo = ksp * per, ch_hi = min(chunks_total, ch_lo + per);
 
     u32x4 ry[C::NLDY], rx[C::NLDX];
-    const char* Yb = reinterpret_cast<const char*>(DY);
-    const char* Xb = reinterpret_cast<const char*>(X);
-    const ptrdiff_t zy = reinterpret_cast<const char*>(P.zeros) - Yb, zx = reinterpret_cast<const char*>(P.zeros) - Xb;
-    const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+    // Global loads go through BUFFER resources (raw, stride 0): the address is SGPR base + one 32-bit VGPR
+    // byte offset, and an offset >= num_records returns zeros in hardware. Out-of-image taps, channel
+    // padding and the pixel tail (rows >= M of dY lie behind num_records by construction) therefore cost a
+    // select of the offset at most -- no 64-bit address arithmetic, no zero-page redirection, no masking of
+    // the data. (This loop was VALU-bound on exactly that arithmetic: ~120 VALU incl. 27 quarter-rate
+    // integer multiplies per 18 MFMAs; with everything but the loop skeleton removed it still took 45 % of
+    // the kernel's time.)
+    constexpr unsigned OOB = 0x80000000u;                                   // tensors are < 2 GiB (checked at launch)
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(DY), 0, (unsigned)((size_t)P.M * P.lddy * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(X), 0, (unsigned)((size_t)P.B * P.Hin * P.Win * P.ldx * sizeof(T)), 0x00020000);
     // pointwise layers: X pixel == dY pixel, no (b, y, x) decomposition at all
     const bool lin = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 && P.Hin == P.Hg &&
                      P.Win == P.Wg;
     // Staging: thread = (pixel pl of the chunk, lane tp among the TPP threads of that pixel); it loads the
-    // 16-byte channel chunks tp, tp+TPP, ... of dY and of X for THAT pixel: one pixel decomposition per
-    // thread per chunk, TPP consecutive threads read a contiguous 16*TPP-byte run.
-    // Loads are unconditional: padding / out-of-range chunks come from the zero page (see y5m_conv.hip).
+    // 16-byte channel chunks tp, tp+TPP, ... of dY and of X for THAT pixel, TPP consecutive threads read a
+    // contiguous 16*TPP-byte run. Per-thread state advances by uniform steps from chunk to chunk.
     const int pl = tid / C::TPP, tp = tid % C::TPP;
-    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
-        const int m = chunk * KCH + pl;
-        const bool mv = m < P.M;
-        bool xin = mv;
-        size_t pix = (size_t)m;
-        if (!lin) {
-            int gx, t, gy, b;
-            fast_divmod(m, P.Wg, rcpW, t, gx);
-            fast_divmod(t, P.Hg, rcpH, b, gy);
-            const int iy = gy * P.sy + dh, ix = gx * P.sx + dw;
-            xin = mv && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            pix = (size_t)(b * P.Hin + iy) * P.Win + ix;
-        }
-        const ptrdiff_t ybase = (ptrdiff_t)(((size_t)m * P.lddy + n0) * sizeof(T));
-        const ptrdiff_t xbase = (ptrdiff_t)((pix * P.ldx + c0) * sizeof(T));
+    // loop-invariant per-load byte offsets inside the pixel row (or OOB for channel padding)
+    unsigned yadd[C::NLDY], xadd[C::NLDX];
+    int xdh[C::NLDX], xdw[C::NLDX];
 #pragma unroll
-        for (int i = 0; i < C::NLDY; ++i) {
-            const int cc = tp + C::TPP * i;
-            const bool yv = mv && cc < C::YCPR && (n0 + cc * CH < P.N);
-            ry[i] = *reinterpret_cast<const u32x4*>(Yb + (yv ? ybase + cc * 16 : zy));
-        }
+    for (int i = 0; i < C::NLDY; ++i) {
+        const int cc = tp + C::TPP * i;
+        yadd[i] = (cc < C::YCPR && n0 + cc * CH < P.N) ? (unsigned)((n0 + cc * CH) * sizeof(T)) : OOB;
+    }
 #pragma unroll
-        for (int i = 0; i < C::NLDX; ++i) {
-            const int cc = tp + C::TPP * i;
-            const bool xv = xin && cc < C::XCPR && (c0 + cc * CH < P.C);
-            rx[i] = *reinterpret_cast<const u32x4*>(Xb + (xv ? xbase + cc * 16 : zx));
+    for (int i = 0; i < C::NLDX; ++i) {
+        const int cc = tp + C::TPP * i;                    // virtual chunk -> (tap tap0 + tl, real channel chunk)
+        const int tl = cc / (C::CBLK / CH);
+        const int tap = tap0 + (tl < TPB ? tl : 0);
+        const int ta = tap / P.tw, tb = tap - ta * P.tw;
+        xdh[i] = P.dh0 + ta * P.dhs;
+        xdw[i] = P.dw0 + tb * P.dws;
+        const int chn = c0 + (cc - tl * (C::CBLK / CH)) * CH;
+        xadd[i] = (cc < C::XCPR && tl < TPB && chn < P.C) ? (unsigned)(chn * sizeof(T)) : OOB;
+    }
+    // pixel m = chunk*KCH + pl as (image gb, row gy*sy, column gx*sx); advanced incrementally per chunk
+    int gx = 0, gy = 0, gb = 0;
+    unsigned yrow, xrow;                                   // byte offsets of dY row m / X row m (pointwise layers)
+    {
+        const int m = ch_lo * KCH + pl;
+        yrow = (unsigned)m * (unsigned)(P.lddy * sizeof(T));
+        xrow = (unsigned)m * (unsigned)(P.ldx * sizeof(T));
+        const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+        int t;
+        fast_divmod(m, P.Wg, rcpW, t, gx);
+        fast_divmod(t, P.Hg, rcpH, gb, gy);
+    }
+    const int stepx = KCH % P.Wg, stepy = (KCH / P.Wg) % P.Hg, stepb = KCH / (P.Wg * P.Hg);
+    const unsigned ystep = (unsigned)(KCH * P.lddy * sizeof(T));
+    const unsigned ldxb = (unsigned)(P.ldx * sizeof(T));
+    auto load_chunk = [&]() __attribute__((always_inline)) {       // loads the chunk the state points at, then advances
+#pragma unroll
+        for (int i = 0; i < C::NLDY; ++i) ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, yrow + yadd[i], 0, 0);
+        if (lin) {
+            // X row == dY row index: same row offset scaled by the X row pitch
+#pragma unroll
+            for (int i = 0; i < C::NLDX; ++i)
+                rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xrow + xadd[i], 0, 0);
+        } else {
+            const int y0 = gy * P.sy, x0 = gx * P.sx, r0 = gb * P.Hin;
+#pragma unroll
+            for (int i = 0; i < C::NLDX; ++i) {
+                const int iy = y0 + xdh[i], ix = x0 + xdw[i];
+                const bool in = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                // < 2^24 pixels (checked at launch): 24-bit multiplies are full rate
+                const unsigned pix = __umul24((unsigned)(r0 + iy), (unsigned)P.Win) + (unsigned)ix;
+                const unsigned off = __umul24(pix, ldxb) + xadd[i];
+                rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, in ? off : OOB, 0, 0);
+            }
         }
+        // advance to the next chunk: m += KCH
+        yrow += ystep;
+        xrow += KCH * ldxb;
+        gx += stepx;
+        const int c1 = gx >= P.Wg ? 1 : 0;
+        gx -= c1 ? P.Wg : 0;
+        gy += stepy + c1;
+        const int c2 = gy >= P.Hg ? 1 : 0;
+        gy -= c2 ? P.Hg : 0;
+        gb += stepb + c2;
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
         unsigned char* Ys = smem + buf * (C::YB + C::XB);
@@ -143,9 +193,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
         }
     };
 
-    f32x4 acc[3][CFR];
+    f32x4 acc[NFR][CFR];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NFR; ++a)
 #pragma unroll
         for (int b = 0; b < CFR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -158,10 +208,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int ks = wk * KS + s;
-                uint4 ya[3], xb[CFR];
+                uint4 ya[NFR], xb[CFR];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * 3 + a) * WG_SUB;
+                for (int a = 0; a < NFR; ++a) {
+                    const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * NFR + a) * WG_SUB;
                     const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
                     ya[a] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
                 }
@@ -172,7 +222,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
                     xb[b] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
                 }
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
+                for (int a = 0; a < NFR; ++a)
 #pragma unroll
                     for (int b = 0; b < CFR; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ya[a]),
@@ -186,13 +236,13 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
 #pragma unroll
             for (int s = 0; s < KK; ++s) {
                 const int kk = wk * KK + s;
-                float ya[3], xb[CFR];
+                float ya[NFR], xb[CFR];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) ya[a] = Yf[(kk * 4 + g) * C::LDY + wn * 48 + a * 16 + i];
+                for (int a = 0; a < NFR; ++a) ya[a] = Yf[(kk * 4 + g) * C::LDY + wn * (16 * NFR) + a * 16 + i];
 #pragma unroll
                 for (int b = 0; b < CFR; ++b) xb[b] = Xf[(kk * 4 + g) * C::LDX + (wc * CFR + b) * 16 + i];
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
+                for (int a = 0; a < NFR; ++a)
 #pragma unroll
                     for (int b = 0; b < CFR; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[a], xb[b], acc[a][b], 0, 0, 0);
@@ -201,13 +251,13 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
     };
 
     if (ch_lo < ch_hi) {
-        load_chunk(ch_lo);
+        load_chunk();
         store_chunk(0);
         __syncthreads();
         int cur = 0;
         for (int chk = ch_lo; chk < ch_hi; ++chk) {
             const bool more = chk + 1 < ch_hi;
-            if (more) load_chunk(chk + 1);
+            if (more) load_chunk();
             compute(cur);
             if (more) store_chunk(cur ^ 1);
             __syncthreads();
@@ -216,26 +266,28 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) 
         // D[n][c]: lane owns n = (lane>>4)*4 + r, c = lane&15 -> atomics coalesced along c
         const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < NFR; ++a)
 #pragma unroll
             for (int b = 0; b < CFR; ++b) {
-                const int c = c0 + (wc * CFR + b) * 16 + i;
+                const int v0 = (wc * CFR + b) * 16;                 // virtual channel of the fragment
+                const int tap = tap0 + v0 / C::CBLK;
+                const int c = c0 + v0 % C::CBLK + i;
                 if (c >= P.C) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 48 + a * 16 + g * 4 + r;
+                    const int n = n0 + wn * (16 * NFR) + a * 16 + g * 4 + r;
                     if (n < P.N) atomicAdd(P.dwgt + (size_t)n * P.lddw + tap * P.C + c, acc[a][b][r]);
                 }
             }
     }
 }
 
-template <typename T, int WN, int WC, int WK, int CFR>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3>
 static int launch_wgrad(WgradParams& P, hipStream_t st) {
-    using C = WgCfg<T, WN, WC, WK, CFR>;
+    using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR>;
     P.tiles_n = (P.N + C::TN - 1) / C::TN;
-    P.tiles_c = (P.C + C::TC - 1) / C::TC;
-    const int taps = P.th * P.tw;
+    P.tiles_c = (P.C + C::CBLK - 1) / C::CBLK;
+    const int taps = (P.th * P.tw) / TPB;                 // tap groups (blocks along the tap axis)
     const int chunks = (P.M + C::KCH - 1) / C::KCH;
     if (P.ksplit <= 0) {
         // fill the chip (~4 blocks per CU) but keep >= 8 chunks per block so the prologue amortises
@@ -245,7 +297,9 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         const int base = P.tiles_n * P.tiles_c * taps;
         // measured (MI355X, B=64): every split adds one f32 atomic per output element, so pointwise layers
         // (few, large output tiles) want ~1 block per CU, 3x3 layers ~4 per CU, the 48x16 stem tile more
-        const int tgt = target > 0 ? target : (taps == 1 ? 320 : (C::TC <= 16 ? 2048 : 1024));
+        // multi-tap tiles are LDS-heavy (1-2 blocks per CU): one resident round
+        const int per_cu = (int)((160 * 1024) / (2 * (size_t)(C::YB + C::XB)));
+        const int tgt = target > 0 ? target : (TPB > 1 ? 256 * (per_cu < 1 ? 1 : per_cu) : (taps == 1 ? 320 : (C::TC <= 16 ? 2048 : 1024)));
         int ks = (tgt + base - 1) / base;
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
@@ -253,7 +307,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     }
     const size_t lds = 2 * (size_t)(C::YB + C::XB);
     const unsigned grid = (unsigned)(P.tiles_n * P.tiles_c * taps * P.ksplit);
-    auto kern = wgrad_kernel<T, WN, WC, WK, CFR>;
+    auto kern = wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, st, P);
@@ -264,10 +318,22 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
 template <typename T>
 static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     const bool n48 = P.N <= 48, c48 = P.C <= 48, c16 = P.C <= 16;
+    static int multitap = -1;                                      // Y5M_WGRAD_MULTITAP=0: one tap per block everywhere
+    if (multitap < 0) { const char* e = getenv("Y5M_WGRAD_MULTITAP"); multitap = (e && e[0] == '0') ? 0 : 1; }
+    const int taps = P.th * P.tw;
+    if (multitap && taps % 9 == 0 && n48 && c16) return launch_wgrad<T, 1, 1, 4, 9, 9>(P, st);      // stem: 48 x (9 taps x 16)
+    // (3 taps x 48 channels per block was measured too: the 108 accumulator registers leave one block per
+    //  CU and the 48-channel 3x3 layers get SLOWER, 254 -> 447 us; only the stem's 16-channel input pays)
     if (n48 && c16) return launch_wgrad<T, 1, 1, 4, 1>(P, st);     // stem: 48 x 16
     if (n48 && c48) return launch_wgrad<T, 1, 1, 4, 3>(P, st);     // 48 x 48
     if (n48) return launch_wgrad<T, 1, 2, 2, 3>(P, st);            // 48 x 96
     if (c48) return launch_wgrad<T, 2, 1, 2, 3>(P, st);            // 96 x 48
+    // wide layers: 192 x 96 block (wave 96 x 48: 9 transposing reads per 18 MFMAs instead of 12 per 9, and
+    // 1.33x fewer staged bytes per MFMA); Y5M_WGRAD_BIG=2: 192 x 192 (wave 96 x 96, one block per CU), 0: off
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("Y5M_WGRAD_BIG"); big = e ? atoi(e) : 1; }
+    if (big == 2 && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6>(P, st);
+    if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
 }
 
@@ -278,6 +344,13 @@ extern "C" int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream) {
     Y5M_REQUIRE(P.zeros != nullptr, "args.zeros (16 zero bytes in device memory) is required");
     Y5M_REQUIRE(P.C % CH == 0 && P.N % CH == 0 && P.ldx % CH == 0 && P.lddy % CH == 0, "channel counts must be multiples of 16 bytes");
     Y5M_REQUIRE(P.M == P.B * P.Hg * P.Wg && P.M > 0, "M");
+    {
+        // buffer-resource addressing: 32-bit byte offsets with the top bit reserved for "out of range"
+        const size_t esz = dtype == Y5M_BF16 ? 2 : 4;
+        Y5M_REQUIRE((size_t)P.M * P.lddy * esz < (1ull << 31), "dY view must be < 2 GiB");
+        Y5M_REQUIRE((size_t)P.B * P.Hin * P.Win * P.ldx * esz < (1ull << 31), "X view must be < 2 GiB");
+        Y5M_REQUIRE((size_t)P.B * P.Hin * P.Win < (1ull << 24), "X must have < 2^24 pixels");
+    }
     hipStream_t st = y5m_stream(stream);
     if (dtype == Y5M_BF16) return dispatch_wgrad<bf16_t>(P, st);
     return dispatch_wgrad<float>(P, st);
