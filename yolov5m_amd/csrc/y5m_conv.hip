@@ -33,29 +33,42 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     const T* __restrict__ W = reinterpret_cast<const T*>(P.w);
 
     // ---- per-thread staging state ------------------------------------------------------------
+    // Global loads go through BUFFER resources (raw, stride 0): address = SGPR base + a 32-bit VGPR byte
+    // offset (+ an SGPR offset for the weights' K position), and an offset >= num_records returns zeros in
+    // hardware. Image-border taps, K padding and the pixel tail cost ONE select of the offset; there is no
+    // 64-bit address arithmetic in the K loop and no data-dependent fix-up after the loads, so all NA+NB
+    // loads of a K step stay in flight under the MFMAs of the previous one. (views are < 2 GiB: y5m_conv
+    // splits larger batches into slabs)
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int ESZ = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(X), 0, (unsigned)((size_t)P.B * P.Hin * P.Win * P.ldin * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(W), 0, (unsigned)((size_t)P.Np * P.Kp * ESZ), 0x00020000);
     const int q = tid & 7, r0 = tid >> 3;
-    int p0[NA], iy0[NA], ix0[NA];
+    int iy0[NA], ix0[NA];
+    unsigned pb[NA];                                  // byte offset of the pixel's row at tap offset (0, 0)
     // pointwise fast path (1x1, stride 1, no padding, same grid): input pixel == output pixel index,
     // no (b, y, x) decomposition (two integer divisions per row) needed
     const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
     const bool lin_in = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 &&
                         P.Hin == P.Hg && P.Win == P.Wg;
+    const unsigned rowb = (unsigned)(P.ldin * ESZ);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + 32 * i;
-        if (lin_in) {
-            p0[i] = m; ix0[i] = 0;
-            iy0[i] = m < P.M ? 0 : -(1 << 28);
-        } else if (m < P.M) {
+        int pv = m, yv = 0, xv = 0;
+        if (!lin_in) {
             int gx, t, gy, b;
-            fast_divmod(m, P.Wg, rcpW, t, gx);
+            fast_divmod(m, P.Wg, rcpW, t, gx);        // rows past M decompose to garbage and are masked by iy0
             fast_divmod(t, P.Hg, rcpH, b, gy);
-            iy0[i] = gy * P.sy;
-            ix0[i] = gx * P.sx;
-            p0[i] = (b * P.Hin + iy0[i]) * P.Win + ix0[i];
-        } else {
-            iy0[i] = -(1 << 28); ix0[i] = 0; p0[i] = 0;
+            yv = gy * P.sy;
+            xv = gx * P.sx;
+            pv = (b * P.Hin + yv) * P.Win + xv;
         }
+        pb[i] = m < P.M ? (unsigned)pv * rowb : 0u;
+        iy0[i] = m < P.M ? yv : -(1 << 28);
+        ix0[i] = xv;
     }
     // K position of this thread's chunk: kk = kt*BK + q*CH -> (tap row ta, tap col tb, channel c)
     int c, ta, tb;
@@ -66,34 +79,31 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         ta = tap / P.tw;
         tb = tap - ta * P.tw;
     }
-    const T* wrow[NB];
+    // weight rows r0 + 32*i of this channel tile: loop-invariant offsets, the K position is an SGPR offset
+    unsigned wb_off[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int r = r0 + 32 * i;
-        wrow[i] = W + (size_t)(n0 + (r < BN ? r : 0)) * P.Kp + q * CH;
+        wb_off[i] = (unsigned)(((size_t)(n0 + (r < BN ? r : 0)) * P.Kp + q * CH) * ESZ);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[NA], rb[NB];
-    // Loads are UNCONDITIONAL: out-of-range / padding chunks read the device zero page (address select
-    // before the load), so there are no exec-masked branches around the loads and no data-dependent
-    // fix-up after them: all NA+NB loads of a tile stay in flight under the MFMAs of the previous tile.
-    // (byte offset of the zero page relative to X: ONE base pointer + a selected 64-bit offset compiles
-    // to a v_cndmask pair and a plain global_load; selecting between two POINTERS made hipcc branch)
-    const ptrdiff_t zoff = reinterpret_cast<const T*>(P.zeros) - X;      // in elements (both 16-byte aligned)
     auto load_tile = [&](int kt) __attribute__((always_inline)) {
         // K padding (ta >= th) is folded into the row offset: the bounds test then fails for every pixel,
         // so there is ONE per-lane condition and no separate (uniform) code path for the padding tile
-        const int dh = ta < P.th ? P.dh0 + ta * P.dhs : (1 << 24), dw = P.dw0 + tb * P.dws;
-        const int doff = dh * P.Win + dw;
+        const int dh = P.dh0 + ta * P.dhs, dw = P.dw0 + tb * P.dws;
+        const int dhb = ta < P.th ? dh : (1 << 24);
+        // (dh*Win + dw)*ldin + c  in bytes; |dh*Win + dw| < 2^23 (checked at launch)
+        const unsigned koff = (unsigned)((__mul24(dh * P.Win + dw, P.ldin) + c) * ESZ);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int iy = iy0[i] + dh, ix = ix0[i] + dw;
+            const int iy = iy0[i] + dhb, ix = ix0[i] + dw;
             const bool v = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            const ptrdiff_t off = v ? (ptrdiff_t)((size_t)(p0[i] + doff) * P.ldin + c) : zoff;
-            ra[i] = *reinterpret_cast<const u32x4*>(X + off);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, v ? pb[i] + koff : OOB, 0, 0);
         }
+        const int ksoff = kt * (BK * ESZ);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt * BK);
+        for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, wb_off[i], ksoff, 0);
     };
     auto advance_k = [&]() __attribute__((always_inline)) {
         c += BK;
@@ -309,6 +319,24 @@ extern "C" int y5m_conv_tile_n(int N) {
 
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st);      // y5m_conv_pw.hip
 
+static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
+    {
+        // short-K pointwise layers stream through the barrier-free kernel (y5m_conv_pw.hip)
+        const int r = y5m_conv_pw_try(P, dtype, st);
+        if (r != 0) return r < 0 ? r : Y5M_OK;
+    }
+    const int BN = y5m_conv_tile_n(P.N);
+    if (dtype == Y5M_BF16) {
+        if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
+        if (BN == 192) return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
+        return launch_conv<bf16_t, 2, 2, 4, 3>(P, st);
+    } else {
+        if (BN == 48) return launch_conv<float, 4, 1, 2, 3>(P, st);
+        if (BN == 192) return launch_conv<float, 2, 2, 4, 6>(P, st);
+        return launch_conv<float, 2, 2, 4, 3>(P, st);
+    }
+}
+
 extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     ConvParams P;
     static_assert(sizeof(P) == sizeof(*args), "abi struct");
@@ -319,23 +347,29 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     Y5M_REQUIRE(P.Cin % CH == 0 && P.ldin % CH == 0, "Cin/ldin must be multiples of the 16-byte chunk");
     Y5M_REQUIRE(P.Kp % BK == 0 && P.Kp >= P.K && P.K == P.th * P.tw * P.Cin, "K padding");
     Y5M_REQUIRE(P.M == P.B * P.Hg * P.Wg && P.M > 0, "M");
-    Y5M_REQUIRE((int64_t)P.B * P.Hin * P.Win < (1ll << 31), "input pixel count overflows int32");
     Y5M_REQUIRE(P.epi == EPI_HEAD || (P.N % 4 == 0 && P.ldout % 4 == 0), "N/ldout must be multiples of 4");
     const int BN = y5m_conv_tile_n(P.N);
     Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
+    Y5M_REQUIRE(P.Np >= (P.N + BN - 1) / BN * BN, "Np (rows of the packed weights) must cover the channel tiles");
     hipStream_t st = y5m_stream(stream);
-    {
-        // short-K pointwise layers stream through the barrier-free kernel (y5m_conv_pw.hip)
-        const int r = y5m_conv_pw_try(P, dtype, st);
-        if (r != 0) return r < 0 ? r : Y5M_OK;
+    // The kernels address the input view with 32-bit byte offsets (buffer resources; the top bit marks
+    // "out of range"), so one launch sees at most 2 GiB of input: larger batches go in slabs of whole images.
+    const size_t esz = dtype == Y5M_BF16 ? 2 : 4;
+    const size_t img_in = (size_t)P.Hin * P.Win * P.ldin * esz;
+    Y5M_REQUIRE(img_in < (1ull << 31) && (size_t)P.Hin * P.Win < (1ull << 22), "one input image must be < 2 GiB and < 2^22 pixels");
+    const int per_slab = (int)(((1ull << 31) - 1) / img_in);
+    if (P.B <= per_slab) return conv_dispatch(P, dtype, st);
+    Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats, "training-mode conv (stats epilogue): input view must be < 2 GiB");
+    for (int b0 = 0; b0 < P.B; b0 += per_slab) {
+        ConvParams S = P;
+        S.B = P.B - b0 < per_slab ? P.B - b0 : per_slab;
+        S.M = S.B * P.Hg * P.Wg;
+        S.in = (const char*)P.in + (size_t)b0 * img_in;
+        if (P.epi == EPI_HEAD) S.out = (char*)P.out + (size_t)b0 * P.naxs * P.Hg * P.Wg * P.nch * sizeof(float);
+        else S.out = (char*)P.out + (size_t)b0 * P.Hout * P.Wout * P.ldout * esz;
+        if (P.res) S.res = (const char*)P.res + (size_t)b0 * P.Hout * P.Wout * P.ldres * esz;
+        const int r = conv_dispatch(S, dtype, st);
+        if (r != Y5M_OK) return r;
     }
-    if (dtype == Y5M_BF16) {
-        if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
-        if (BN == 192) return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
-        return launch_conv<bf16_t, 2, 2, 4, 3>(P, st);
-    } else {
-        if (BN == 48) return launch_conv<float, 4, 1, 2, 3>(P, st);
-        if (BN == 192) return launch_conv<float, 2, 2, 4, 6>(P, st);
-        return launch_conv<float, 2, 2, 4, 3>(P, st);
-    }
+    return Y5M_OK;
 }
