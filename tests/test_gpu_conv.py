@@ -173,3 +173,113 @@ def test_conv_wgrad(case, dtype):
     y.backward(dy)
     got = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, dtype).cpu()
     assert _relerr(got, w.grad) < TOL[dtype], (case, dtype, _relerr(got, w.grad))
+
+
+# ---- training-mode BatchNorm helpers (y5m_bn_finalize / y5m_bn_act / y5m_bn_bwd) against torch fp32 ----
+BN_CASES = [
+    # M (pixels), C, ld (row pitch >= C: concat-slice views)
+    (1000, 48, 48),
+    (5000, 96, 192),
+    (4099, 192, 192),
+    (777, 384, 768),
+    (300, 768, 768),
+    (70000, 48, 48),
+]
+
+
+def _bn_inputs(M, C, ld, seed):
+    y = _rand((M, ld), seed, -2.0, 2.0)
+    dz = _rand((M, ld), seed + 1, -1.0, 1.0)
+    gamma, beta = _rand((C,), seed + 2, 0.5, 1.5), _rand((C,), seed + 3, -0.3, 0.3)
+    return y, dz, gamma, beta
+
+
+@pytest.mark.parametrize("case", BN_CASES)
+def test_bn_finalize_from_partials(case):
+    """per-tile (sum, sumsq) partials [rows][2][Np] -> mean/var/scale/shift + running stats (momentum 0.03,
+    unbiased running variance), as nn.BatchNorm2d in train mode. Several different inputs go through the SAME
+    workspace back to back: the cross-workgroup hand-off (stage rows + ticket counters) must never serve a
+    stale value and must leave the counters at zero."""
+    from yolov5m_amd import _lib
+    M, C, _ = case
+    L = _lib.lib()
+    Np = (C + 95) // 96 * 96
+    rows = (M + 127) // 128
+    d = lambda t: t.to(DEV).contiguous()
+    wsb = L.y5m_bn_finalize_workspace_bytes(Np)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    out = torch.zeros((4, C), device=DEV)
+    for seed in (51, 151, 251, 351):
+        y = _rand((M, C), seed, -2.0, 2.0) * (1.0 + seed / 100.0) + seed / 200.0
+        pad = rows * 128 - M
+        yp = torch.cat([y, torch.zeros((pad, C))]) if pad else y
+        blk = yp.view(rows, 128, C)
+        part = torch.zeros((rows, 2, Np))
+        part[:, 0, :C] = blk.sum(1)
+        part[:, 1, :C] = (blk * blk).sum(1)
+        gamma, beta = _rand((C,), seed + 1, 0.5, 1.5), _rand((C,), seed + 2, -0.3, 0.3)
+        rm, rv = _rand((C,), seed + 3), _rand((C,), seed + 4, 0.5, 1.5)
+        bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03)
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+        bn.train()
+        bn(y.t().reshape(1, C, M, 1))
+        mean = y.double().mean(0)
+        var = y.double().var(0, unbiased=False)
+        partd, g_, b_, rm_, rv_ = d(part), d(gamma), d(beta), d(rm), d(rv)
+        _lib.check(L.y5m_bn_finalize(_lib.ptr(partd), rows, Np, C, M, _lib.ptr(g_), _lib.ptr(b_), _lib.ptr(rm_), _lib.ptr(rv_),
+                                     0.03, 1e-3, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                     1, _lib.ptr(ws), wsb, _lib.stream_ptr()), "bn_finalize")
+        torch.cuda.synchronize()
+        invstd = 1.0 / torch.sqrt(var + 1e-3)
+        np.testing.assert_allclose(out[2].cpu().numpy(), mean.float().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out[3].cpu().numpy(), invstd.float().numpy(), rtol=1e-4)
+        np.testing.assert_allclose(out[0].cpu().numpy(), (gamma * invstd.float()).numpy(), rtol=1e-4)
+        np.testing.assert_allclose(out[1].cpu().numpy(), (beta - mean.float() * gamma * invstd.float()).numpy(), rtol=2e-4, atol=1e-4)
+        np.testing.assert_allclose(rm_.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rv_.cpu().numpy(), bn.running_var.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", BN_CASES)
+def test_bn_act_and_backward(case, dtype):
+    """z = silu(y*scale + shift) and its autograd (dy, dgamma, dbeta) with batch statistics, through
+    strided (ptr, ld) views"""
+    from yolov5m_amd import _lib
+    from yolov5m_amd._lib import F32, BF16, ACT_SILU
+    M, C, ld = case
+    L = _lib.lib()
+    tdt, dt = (torch.float32, F32) if dtype == "f32" else (torch.bfloat16, BF16)
+    y, dz, gamma, beta = _bn_inputs(M, C, ld, 61)
+    y, dz = _q(y, dtype), _q(dz, dtype)
+    yc = y[:, :C].clone().double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = yc.mean(0), yc.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    z = F.silu((yc - mean) * invstd * g64 + b64)
+    z.backward(dz[:, :C].double())
+    scale = (gamma.double() * invstd.detach()).float()
+    shift = (beta.double() - mean.detach() * gamma.double() * invstd.detach()).float()
+    d = lambda t: t.to(DEV).contiguous()
+    yd, dzd = d(y.to(tdt)), d(dz.to(tdt))
+    sc, sh, mu, is_ = d(scale), d(shift), d(mean.detach().float()), d(invstd.detach().float())
+    # forward
+    out = torch.zeros((M, ld), dtype=tdt, device=DEV)
+    _lib.check(L.y5m_bn_act(_lib.ptr(yd), ld, _lib.ptr(sc), _lib.ptr(sh), None, 0, _lib.ptr(out), ld, M, C, ACT_SILU, dt,
+                            _lib.stream_ptr()), "bn_act")
+    assert _relerr(out[:, :C].float().cpu(), z.detach().float()) < (1e-5 if dtype == "f32" else 1e-2)
+    assert float(out[:, C:].float().abs().max()) == 0.0 if ld > C else True      # neighbours of the view untouched
+    # backward
+    dy = torch.zeros((M, C), dtype=tdt, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    wsb = L.y5m_bn_bwd_workspace_bytes(M, C)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    for _ in range(2):
+        _lib.check(L.y5m_bn_bwd(_lib.ptr(dzd), ld, _lib.ptr(yd), ld, _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(mu), _lib.ptr(is_),
+                                M, C, ACT_SILU, _lib.ptr(dg), _lib.ptr(db), 0, _lib.ptr(dy), C, _lib.ptr(ws), wsb, dt,
+                                _lib.stream_ptr()), "bn_bwd")
+        torch.cuda.synchronize()
+        tol = 2e-4 if dtype == "f32" else 2e-2
+        assert _relerr(dy.float().cpu(), yc.grad.float()) < tol
+        assert _relerr(dg.cpu(), g64.grad.float()) < 2e-4
+        assert _relerr(db.cpu(), b64.grad.float()) < 2e-4

@@ -176,94 +176,132 @@ extern "C" int y5m_s2d_input(const float* img, int B, int H, int W, void* out, i
 // =================================================================================================
 // stats [tiles_m][2][Np] (sum, sumsq) -> mean, biased var; scale = g*invstd, shift = b - mean*scale;
 // running stats: momentum, UNBIASED variance (reference model.py:17, nn.BatchNorm2d semantics)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int tiles_m, int Np, int C,
-                                                         double count, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ rmean,
-                                                         float* __restrict__ rvar, float momentum, float eps,
-                                                         float* __restrict__ scale, float* __restrict__ shift,
-                                                         float* __restrict__ mean_o, float* __restrict__ invstd_o,
-                                                         int update_running) {
-    __shared__ double s1[16][17], s2[16][17];
-    const int cs = threadIdx.x & 15, rs = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cs;
-    double a = 0.0, b = 0.0;
-    if (c < C) {
-        for (int t = rs; t < tiles_m; t += 16) {
-            a += (double)stats[((size_t)t * 2 + 0) * Np + c];
-            b += (double)stats[((size_t)t * 2 + 1) * Np + c];
-        }
-    }
-    s1[rs][cs] = a; s2[rs][cs] = b;
-    __syncthreads();
-    if (rs == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) { a += s1[r][cs]; b += s2[r][cs]; }
-        const double mean = a / count;
-        double var = b / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
-        mean_o[c] = (float)mean;
-        invstd_o[c] = invstd;
-        if (update_running) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
-            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
-        }
-    }
-}
+//
+// ONE launch: every block reduces a row range of the partials (64 channels x 4 row lanes, coalesced
+// 256-byte rows) into stage[S][2][C]; the block that takes the LAST ticket of its channel group then sums
+// the S stage rows in a fixed order (f64) and finalises -- deterministic whatever the arrival order.
+// ctr[] (one counter per 64-channel group) must be zero on entry and is left zero.
+struct BnFinArgs {
+    double count;
+    const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps;
+    float* scale; float* shift; float* mean_o; float* invstd_o; int update_running;
+};
+struct BnBwdFinArgs {
+    const float* scale; const float* mean; const float* invstd; float invM;
+    float* cB; float* cD; float* dgamma; float* dbeta; int accumulate;
+};
 
-// stage 1 of long column reductions: in [R][2][ld] -> out [S][2][ld], S = gridDim.x row splits.
-// Threads run along channels (coalesced 256-byte rows), 4 row lanes per block, fixed order.
-#define CR_SPLITS 256
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ in, int R, int ld, int C,
-                                                       float* __restrict__ out) {
-    __shared__ float sm[2][4][64];
+// [R][2][ld] partial sums -> per-channel totals -> finalise (MODE 0: forward statistics, MODE 1: backward
+// coefficients). 1024 threads = 64 channels x 16 row lanes; gridDim.x = S row splits (<= 64).
+template <int MODE>
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ in, int R, int ld, int C,
+                                                                 float* __restrict__ stage, unsigned* __restrict__ ctr,
+                                                                 BnFinArgs F, BnBwdFinArgs G) {
+    __shared__ float sm[2][16][64];
+    __shared__ double sd[2][16][64];
+    __shared__ int s_last;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    const int chunk = (R + gridDim.x - 1) / gridDim.x;
+    const int S = gridDim.x;
+    const int chunk = (R + S - 1) / S;
     const int r0 = blockIdx.x * chunk, r1 = min(R, r0 + chunk);
     float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int r = r0 + rl; r < r1; r += 4) {
+    if (c < C) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 16) {
             a += in[((size_t)r * 2 + 0) * ld + c];
             b += in[((size_t)r * 2 + 1) * ld + c];
         }
+    }
     sm[0][rl][cl] = a; sm[1][rl][cl] = b;
     __syncthreads();
+    // Cross-workgroup hand-off WITHOUT a device-scope fence: __threadfence() is a write-back of the whole
+    // (per-XCD, non-coherent) L2 on gfx950 -- tens of microseconds right after a conv that dirtied it. The
+    // few stage floats are instead written / read with agent-scope relaxed atomics (sc1: written through to,
+    // and read from, the memory side), ordered against the ticket by the stores' own completion
+    // (workgroup-scope release = s_waitcnt vmcnt(0), then the barrier, then the agent-scope ticket).
     if (rl < 2 && c < C) {
-        const float t = (sm[rl][0][cl] + sm[rl][1][cl]) + (sm[rl][2][cl] + sm[rl][3][cl]);
-        out[((size_t)blockIdx.x * 2 + rl) * ld + c] = t;
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += sm[rl][l][cl];
+        __hip_atomic_store(stage + ((size_t)blockIdx.x * 2 + rl) * C + c, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the block that takes the last ticket of this channel group finalises ---------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = (__hip_atomic_fetch_add(ctr + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)S - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    double da = 0.0, db = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = rl; r < S; r += 16) {
+            da += (double)__hip_atomic_load(stage + ((size_t)r * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            db += (double)__hip_atomic_load(stage + ((size_t)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    sd[0][rl][cl] = da; sd[1][rl][cl] = db;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ctr + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rl != 0 || c >= C) return;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { da += sd[0][l][cl]; db += sd[1][l][cl]; }
+    if constexpr (MODE == 0) {
+        const double mean = da / F.count;
+        double var = db / F.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)F.eps));
+        const float sc = F.gamma[c] * invstd;
+        F.scale[c] = sc;
+        F.shift[c] = F.beta[c] - (float)mean * sc;
+        F.mean_o[c] = (float)mean;
+        F.invstd_o[c] = invstd;
+        if (F.update_running) {
+            const double unb = F.count > 1.0 ? var * F.count / (F.count - 1.0) : var;
+            F.rmean[c] = (1.0f - F.momentum) * F.rmean[c] + F.momentum * (float)mean;
+            F.rvar[c] = (1.0f - F.momentum) * F.rvar[c] + F.momentum * (float)unb;
+        }
+    } else {
+        const float mu = G.mean[c], is = G.invstd[c], sc = G.scale[c];
+        const float dbeta = (float)da;
+        const float dgamma = is * (float)(db - (double)mu * da);
+        const float cB = -sc * dgamma * is * G.invM;
+        G.cB[c] = cB;
+        G.cD[c] = -sc * dbeta * G.invM - cB * mu;
+        if (G.dgamma && G.dbeta) {
+            if (G.accumulate) { G.dbeta[c] += dbeta; G.dgamma[c] += dgamma; }
+            else { G.dbeta[c] = dbeta; G.dgamma[c] = dgamma; }
+        }
     }
 }
 
-// returns the (pointer, rows) the finalize kernel should read: either the input or the stage-1 output
-static int colreduce_if_long(const float*& part, int& R, int ld, int C, float* ws, hipStream_t st) {
-    if (R <= 2 * CR_SPLITS) return Y5M_OK;
-    hipLaunchKernelGGL(colreduce_kernel, dim3(CR_SPLITS, (unsigned)((C + 63) / 64)), dim3(256), 0, st, part, R, ld, C, ws);
-    Y5M_CHECK_LAUNCH("colreduce_kernel");
-    part = ws;
-    R = CR_SPLITS;
-    return Y5M_OK;
+#define BN_SPLITS 64       // max row splits (= stage rows) of a fused reduce + finalise launch
+static inline int bn_splits(int64_t R) {
+    int64_t s = (R + 15) / 16;                 // >= one row per row lane
+    return (int)(s < 1 ? 1 : (s > BN_SPLITS ? BN_SPLITS : s));
 }
+static inline size_t bn_stage_bytes(int C) { return y5m_align((size_t)BN_SPLITS * 2 * (size_t)C * sizeof(float)); }
+static inline size_t bn_ctr_bytes(int C) { return y5m_align(((size_t)C / 64 + 2) * sizeof(unsigned)); }
 
-extern "C" size_t y5m_bn_finalize_workspace_bytes(int Np) { return (size_t)CR_SPLITS * 2 * (size_t)Np * sizeof(float) + 256; }
+extern "C" size_t y5m_bn_finalize_workspace_bytes(int Np) { return bn_stage_bytes(Np) + bn_ctr_bytes(Np); }
 
+// ws: zero-filled by the caller before its FIRST use (ticket counters; every call leaves them zero); one
+// call at a time per workspace.
 extern "C" int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, int64_t count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* mean_out, float* invstd_out, int update_running,
                                void* ws, size_t ws_bytes, void* stream) {
     if (ws_bytes < y5m_bn_finalize_workspace_bytes(Np)) { y5m_set_error("bn_finalize ws too small"); return Y5M_EWS; }
+    Y5M_REQUIRE(C <= Np, "C <= Np");
     hipStream_t st = y5m_stream(stream);
-    const float* part = stats;
-    int R = tiles_m;
-    const int rc = colreduce_if_long(part, R, Np, C, reinterpret_cast<float*>(ws), st);
-    if (rc != Y5M_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, part, R, Np, C,
-                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out,
-                       invstd_out, update_running);
-    Y5M_CHECK_LAUNCH("bn_finalize_kernel");
+    float* stage = reinterpret_cast<float*>(ws);
+    unsigned* ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + bn_stage_bytes(Np));
+    BnFinArgs F{(double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, update_running};
+    BnBwdFinArgs G{};
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<0>, dim3((unsigned)bn_splits(tiles_m), (unsigned)((C + 63) / 64)), dim3(1024), 0,
+                       st, stats, tiles_m, Np, C, stage, ctr, F, G);
+    Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
     return Y5M_OK;
 }
 
@@ -284,39 +322,76 @@ extern "C" int y5m_bn_fold(const float* gamma, const float* beta, const float* r
     return Y5M_OK;
 }
 
-// z = act(y*scale + shift) (+ res) ; one thread = 8 channels of one pixel
+// ---- row-loop geometry of the BN elementwise kernels --------------------------------------------------
+// A block covers CG 16-byte channel chunks x RP = 256/CG pixels per pass and walks the pixels with a grid
+// stride: a thread keeps ITS chunk's per-channel coefficients in registers for the whole kernel (they were
+// re-loaded per pixel before: 6 parameter vectors per 2 data vectors) and has U independent rows in flight.
+struct EwGeom { int CG, groups, RP; unsigned gx; };
+static inline EwGeom ew_geom(int64_t M, int C8, int max_gx) {
+    EwGeom g;
+    g.CG = 1;
+    for (int d = C8 < 32 ? C8 : 32; d >= 1; --d) if (C8 % d == 0) { g.CG = d; break; }
+    g.groups = C8 / g.CG;
+    g.RP = 256 / g.CG;
+    int64_t gx = (M + g.RP - 1) / g.RP;
+    const int64_t cap = max_gx / g.groups > 0 ? max_gx / g.groups : 1;
+    g.gx = (unsigned)(gx < 1 ? 1 : (gx > cap ? cap : gx));
+    return g;
+}
+
+// z = act(y*scale + shift) (+ res)
 template <typename T>
-__global__ void bn_act_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
-                              const float* __restrict__ shift, const T* __restrict__ res, int ldres, T* __restrict__ out,
-                              int ldout, int64_t M, int C8, int act) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * C8) return;
-    const int64_t m = i / C8;
-    const int c = (int)(i - m * C8) * 8;
-    float v[8], sc[8], sh[8];
-    load8<T>(y + m * ldy + c, v);
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const T* __restrict__ res, int ldres,
+                                                    T* __restrict__ out, int ldout, int64_t M, int CG, int RP, int act) {
+    const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
+    if (rl >= RP) return;
+    const int c = (blockIdx.y * CG + cl) * 8;
+    float sc[8], sh[8];
     load8<float>(scale + c, sc);
     load8<float>(shift + c, sh);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        v[k] = v[k] * sc[k] + sh[k];
-        if (act == Y5M_ACT_SILU) v[k] = silu_f(v[k]);
-    }
-    if (res) {
+    const int64_t stride = (int64_t)gridDim.x * RP;
+    auto one = [&](int64_t m) __attribute__((always_inline)) {
+        float v[8];
+        load8<T>(y + m * ldy + c, v);
         float r[8];
-        load8<T>(res + m * ldres + c, r);
+        if (res) load8<T>(res + m * ldres + c, r);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += r[k];
+        for (int k = 0; k < 8; ++k) {
+            v[k] = v[k] * sc[k] + sh[k];
+            if (act == Y5M_ACT_SILU) v[k] = silu_f(v[k]);
+            if (res) v[k] += r[k];
+        }
+        store8<T>(out + m * ldout + c, v);
+    };
+    int64_t m = (int64_t)blockIdx.x * RP + rl;
+    for (; m + 3 * stride < M; m += 4 * stride) {
+        float v[4][8], r[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load8<T>(y + (m + u * stride) * ldy + c, v[u]);
+            if (res) load8<T>(res + (m + u * stride) * ldres + c, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[u][k] = v[u][k] * sc[k] + sh[k];
+                if (act == Y5M_ACT_SILU) v[u][k] = silu_f(v[u][k]);
+                if (res) v[u][k] += r[u][k];
+            }
+            store8<T>(out + (m + u * stride) * ldout + c, v[u]);
+        }
     }
-    store8<T>(out + m * ldout + c, v);
+    for (; m < M; m += stride) one(m);
 }
 
 extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
                           void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream) {
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
-    const int64_t n = M * (C / 8);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream),
-                                         (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, C / 8, act);)
+    const EwGeom g = ew_geom(M, C / 8, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<T>, dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
+                                         (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act);)
     Y5M_CHECK_LAUNCH("bn_act_kernel");
     return Y5M_OK;
 }
@@ -324,145 +399,155 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
 // =================================================================================================
 // BatchNorm + SiLU backward
 //   t = y*scale + shift ; z = silu(t) ; dt = dz * silu'(t) ; xhat = (y - mean)*invstd
-//   dbeta = sum dt ; dgamma = sum dt*xhat ; dy = gamma*invstd*(dt - dbeta/M - xhat*dgamma/M)
+//   dbeta = sum dt ; dgamma = sum dt*xhat = invstd*(sum dt*y - mean*sum dt)
+//   dy = gamma*invstd*(dt - dbeta/M - xhat*dgamma/M) = scale*dt + cB*y + cD
+//        cB = -scale*dgamma*invstd/M ; cD = -scale*dbeta/M - cB*mean            (scale = gamma*invstd)
+// Three launches: (1) reduce (sum dt, sum dt*y) -> <= 512 partial rows, (2) bn_reduce_finalize_kernel<1>:
+// dgamma/dbeta and the apply coefficients cB/cD, (3) apply.
 // =================================================================================================
 __device__ __forceinline__ float silu_grad(float t) {
     const float s = 1.0f / (1.0f + __expf(-t));
     return s * (1.0f + t * (1.0f - s));
 }
 
-#define BNR_ROWS 256   // pixels per block in the reduce pass
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                            int ldy, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, int64_t M, int C, int act,
-                                                           float* __restrict__ part) {
-    // block = 256 threads: (C8 chunk lanes) x (row lanes); grid.x = row blocks, grid.y = channel groups of 64
-    __shared__ float sm[2][32][65];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;      // 8 chunks (64 ch) x 32 row lanes
-    const int c = blockIdx.y * 64 + cl * 8;
-    const int64_t m0 = (int64_t)blockIdx.x * BNR_ROWS;
-    float sb[8], sg[8];
+                                                           const float* __restrict__ shift, int64_t M, int C, int CG, int RP,
+                                                           int act, float* __restrict__ part) {
+    __shared__ float sm[2][256][9];            // [which][thread][k] (+1: the 8-float rows land on distinct banks)
+    const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const bool active = rl < RP;
+    const int c = (blockIdx.y * CG + cl) * 8;
+    float s1[8], s2[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sb[k] = 0.f; sg[k] = 0.f; }
-    if (c < C) {
-        float sc[8], sh[8], mu[8], is[8];
-        load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(mean + c, mu); load8<float>(invstd + c, is);
-        for (int r = rl; r < BNR_ROWS; r += 32) {
-            const int64_t m = m0 + r;
-            if (m >= M) break;
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    if (active) {
+        float sc[8], sh[8];
+        load8<float>(scale + c, sc);
+        load8<float>(shift + c, sh);
+        const int64_t stride = (int64_t)gridDim.x * RP;
+        int64_t m = (int64_t)blockIdx.x * RP + rl;
+        for (; m + 3 * stride < M; m += 4 * stride) {
+            float g[4][8], yv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                load8<T>(dz + (m + u * stride) * lddz + c, g[u]);
+                load8<T>(y + (m + u * stride) * ldy + c, yv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float dt = act == Y5M_ACT_SILU ? g[u][k] * silu_grad(yv[u][k] * sc[k] + sh[k]) : g[u][k];
+                    s1[k] += dt;
+                    s2[k] += dt * yv[u][k];
+                }
+        }
+        for (; m < M; m += stride) {
             float g[8], yv[8];
             load8<T>(dz + m * lddz + c, g);
             load8<T>(y + m * ldy + c, yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float t = yv[k] * sc[k] + sh[k];
-                const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(t) : g[k];
-                sb[k] += dt;
-                sg[k] += dt * ((yv[k] - mu[k]) * is[k]);
+                const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
+                s1[k] += dt;
+                s2[k] += dt * yv[k];
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sm[0][rl][cl * 8 + k] = sb[k]; sm[1][rl][cl * 8 + k] = sg[k]; }
+    for (int k = 0; k < 8; ++k) { sm[0][threadIdx.x][k] = s1[k]; sm[1][threadIdx.x][k] = s2[k]; }
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) t += sm[which][r][ch];
-        const int cc = blockIdx.y * 64 + ch;
-        if (cc < C) part[((size_t)blockIdx.x * 2 + which) * C + cc] = t;
+    // block partial: NCH = CG*8 channels x 2 sums, summed over the RP row lanes in a fixed order
+    const int NCH = CG * 8;
+    for (int t = threadIdx.x; t < 2 * NCH; t += 256) {
+        const int which = t / NCH, ch = t - which * NCH;
+        float acc = 0.f;
+        for (int r = 0; r < RP; ++r) acc += sm[which][r * CG + (ch >> 3)][ch & 7];
+        part[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * NCH + ch] = acc;
     }
 }
 
-// sums -> (sbeta, sgamma) for the apply pass AND the parameter gradients (written or accumulated)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C,
-                                                             float* __restrict__ sgamma, float* __restrict__ sbeta,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             int accumulate) {
-    __shared__ double s1[16][17], s2[16][17];
-    const int cs = threadIdx.x & 15, rs = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cs;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int t = rs; t < nblk; t += 16) {
-            a += (double)part[((size_t)t * 2 + 0) * ld + c];
-            b += (double)part[((size_t)t * 2 + 1) * ld + c];
-        }
-    s1[rs][cs] = a; s2[rs][cs] = b;
-    __syncthreads();
-    if (rs == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) { a += s1[r][cs]; b += s2[r][cs]; }
-        sbeta[c] = (float)a; sgamma[c] = (float)b;
-        if (dgamma && dbeta) {
-            if (accumulate) { dbeta[c] += (float)a; dgamma[c] += (float)b; }
-            else { dbeta[c] = (float)a; dgamma[c] = (float)b; }
-        }
-    }
-}
-
-// dy = gamma*invstd*(dt - sb/M - xhat*sg/M)  where (sb, sg) are THIS step's sums (part finalised in ws)
+// dy = scale*dt + cB*y + cD
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
-                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ sbeta, const float* __restrict__ sgamma, float invM,
-                                    T* __restrict__ dy, int lddy, int64_t M, int C8, int act) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * C8) return;
-    const int64_t m = i / C8;
-    const int c = (int)(i - m * C8) * 8;
-    float g[8], yv[8], sc[8], sh[8], mu[8], is[8], sb[8], sg[8];
-    load8<T>(dz + m * lddz + c, g);
-    load8<T>(y + m * ldy + c, yv);
-    load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(mean + c, mu); load8<float>(invstd + c, is);
-    load8<float>(sbeta + c, sb); load8<float>(sgamma + c, sg);
-    float o[8];
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ cB, const float* __restrict__ cD,
+                                                          T* __restrict__ dy, int lddy, int64_t M, int CG, int RP, int act) {
+    const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
+    if (rl >= RP) return;
+    const int c = (blockIdx.y * CG + cl) * 8;
+    float sc[8], sh[8], kb[8], kd[8];
+    load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(cB + c, kb); load8<float>(cD + c, kd);
+    const int64_t stride = (int64_t)gridDim.x * RP;
+    int64_t m = (int64_t)blockIdx.x * RP + rl;
+    for (; m + 3 * stride < M; m += 4 * stride) {
+        float g[4][8], yv[4][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float t = yv[k] * sc[k] + sh[k];
-        const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(t) : g[k];
-        const float xh = (yv[k] - mu[k]) * is[k];
-        o[k] = sc[k] * (dt - sb[k] * invM - xh * sg[k] * invM);     // scale = gamma*invstd
+        for (int u = 0; u < 4; ++u) {
+            load8<T>(dz + (m + u * stride) * lddz + c, g[u]);
+            load8<T>(y + (m + u * stride) * ldy + c, yv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dt = act == Y5M_ACT_SILU ? g[u][k] * silu_grad(yv[u][k] * sc[k] + sh[k]) : g[u][k];
+                o[k] = sc[k] * dt + (kb[k] * yv[u][k] + kd[k]);
+            }
+            store8<T>(dy + (m + u * stride) * lddy + c, o);
+        }
     }
-    store8<T>(dy + m * lddy + c, o);
+    for (; m < M; m += stride) {
+        float g[8], yv[8], o[8];
+        load8<T>(dz + m * lddz + c, g);
+        load8<T>(y + m * ldy + c, yv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
+            o[k] = sc[k] * dt + (kb[k] * yv[k] + kd[k]);
+        }
+        store8<T>(dy + m * lddy + c, o);
+    }
 }
 
+#define BNR_MAX_GX 512     // partial rows of the backward reduce (gx * groups <= 512 blocks: 2 per CU)
 extern "C" size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C) {
-    const size_t nblk = (size_t)((M + BNR_ROWS - 1) / BNR_ROWS);
-    return y5m_align(nblk * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + y5m_align((size_t)CR_SPLITS * 2 * C * 4) + 256;
+    return y5m_align((size_t)BNR_MAX_GX * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + bn_stage_bytes(C) + bn_ctr_bytes(C);
 }
 
 // Full BN+SiLU backward of one CBL: param grads (dgamma, dbeta: accumulate flag) and dy.
+// ws: zero-filled by the caller before its FIRST use (ticket counters; every call leaves them zero); one
+// call at a time per workspace.
 extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
                           float* dbeta, int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes,
                           int dtype, void* stream) {
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     if (ws_bytes < y5m_bn_bwd_workspace_bytes(M, C)) { y5m_set_error("bn_bwd ws too small"); return Y5M_EWS; }
-    int nblk = (int)((M + BNR_ROWS - 1) / BNR_ROWS);
-    float* part = reinterpret_cast<float*>(ws);
-    char* p1 = reinterpret_cast<char*>(ws) + y5m_align((size_t)nblk * 2 * C * 4);
-    float* sums = reinterpret_cast<float*>(p1);
-    float* stage = reinterpret_cast<float*>(p1 + y5m_align((size_t)2 * C * 4));
-    float* sbeta = sums, *sgamma = sums + C;
+    char* w = reinterpret_cast<char*>(ws);
+    float* part = reinterpret_cast<float*>(w);
+    w += y5m_align((size_t)BNR_MAX_GX * 2 * C * 4);
+    float* cB = reinterpret_cast<float*>(w), *cD = cB + C;
+    w += y5m_align((size_t)2 * C * 4);
+    float* stage = reinterpret_cast<float*>(w);
+    unsigned* ctr = reinterpret_cast<unsigned*>(w + bn_stage_bytes(C));
     hipStream_t st = y5m_stream(stream);
-    const dim3 rgrid((unsigned)nblk, (unsigned)((C + 63) / 64));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, rgrid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y,
-                                         ldy, scale, shift, mean, invstd, M, C, act, part);)
+    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(256), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, M, C, gr.CG, gr.RP, act, part);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    const float* pp = part;
-    const int rc = colreduce_if_long(pp, nblk, C, C, stage, st);
-    if (rc != Y5M_OK) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, pp, nblk, C, C, sgamma,
-                       sbeta, dgamma, dbeta, accumulate_param_grads);
-    Y5M_CHECK_LAUNCH("bn_bwd_finalize_kernel");
-    const int64_t n = M * (C / 8);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)dz, lddz,
-                                         (const T*)y, ldy, scale, shift, mean, invstd, sbeta, sgamma, 1.0f / (float)M,
-                                         (T*)dy, lddy, M, C / 8, act);)
+    BnFinArgs F{};
+    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads};
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)bn_splits(gr.gx), (unsigned)((C + 63) / 64)), dim3(1024), 0,
+                       st, part, (int)gr.gx, C, C, stage, ctr, F, G);
+    Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
+    const EwGeom ga = ew_geom(M, C / 8, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (T*)dy, lddy, M, ga.CG,
+                                         ga.RP, act);)
     Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return Y5M_OK;
 }
