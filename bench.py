@@ -33,6 +33,27 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak
 FWD_GFLOP_PER_IMAGE_640 = 48.872
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the conv kernels from the committed PMC summary (profiles/rNN_pmc_bench.json,
+    produced by tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, gfx950 x2 on fetch).
+    bench.py cannot run rocprofv3 on itself, so this is the last committed measurement of the same workload
+    (B=64 @ 640x640) or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        tot = n = 0.0
+        for name in ("conv_igemm_kernel", "conv_pw_kernel"):
+            if name in k:
+                tot += k[name]["hbm_bytes_per_launch"] * k[name]["launches"]
+                n += k[name]["launches"]
+        return round(tot / n) if n else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(B=4, size=640, steps=2):
     """CPU leg: the oracle restatement of the reference path (model fwd, ComputeLoss, autograd bwd,
     clip, Adam) on the host cores. kind = "port". Bounded: B=4, 1 warm-up + `steps` timed steps."""
@@ -201,9 +222,10 @@ def main():
         achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
         wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
         out["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_kernel<bf16> (forward conv + data gradient, all launches of one step)",
+            "bound": "mfma", "kernel": "y5m_conv: conv_igemm_kernel<bf16> + conv_pw_kernel (forward conv + data gradient, all "
+                                       "launches of one step)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
             "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1),
             "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},

@@ -129,6 +129,23 @@ def test_pointwise_fused_epilogue(case, res):
     assert _relerr(got, ref) < TOL["bf16"]
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], (2, 96, 48, 50, 96, 1, 1, 0)])
+def test_conv_dgrad_fused_residual_source(case, dtype):
+    """dx = src + dgrad with src in its own tensor (bottleneck residual gradient fused into the first conv's
+    data gradient), stride 1 and the four parity classes of stride 2"""
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    x = _rand((B, Cin, H, W), 71).requires_grad_(True)
+    w = _q(_rand((Cout, Cin, k, k), 72, -0.2, 0.2), dtype)
+    y = F.conv2d(x, w, None, s, p)
+    dy = _q(_rand(tuple(y.shape), 73), dtype)
+    y.backward(dy)
+    src = _q(_rand((B, Cin, H, W), 74), dtype)
+    got = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), s, p, dtype, src=src.to(DEV)).cpu()
+    assert _relerr(got, x.grad + src) < TOL[dtype]
+
+
 @pytest.mark.parametrize("acc", [False, True])
 @pytest.mark.parametrize("case", PW_CASES)
 def test_pointwise_dgrad(case, acc):

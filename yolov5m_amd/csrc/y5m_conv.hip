@@ -271,8 +271,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
                     for (int r = 0; r < 4; ++r) v[r] += rv[r];
                 }
             } else if (P.epi == EPI_DGRAD && P.accumulate) {
+                // out = conv + (res ? res : out): `res` lets the first accumulation read ANOTHER tensor of the
+                // output's shape (the bottleneck's residual gradient) instead of a copy made beforehand
                 float ov[4];
-                load4<T>(o, ov);
+                load4<T>(P.res ? reinterpret_cast<const T*>(P.res) + opix * P.ldres + n : o, ov);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += ov[r];
             }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
         // the wait for `old` then leaves the prefetch in flight
         u32x2 old[OLD ? NCF : 1];
         if constexpr (OLD) {
-            const bf16_t* src = EPI == EPI_DGRAD ? o : reinterpret_cast<const bf16_t*>(P.res) + p * P.ldres + cbase;
+            const bf16_t* src = (EPI == EPI_DGRAD && !P.res) ? o : reinterpret_cast<const bf16_t*>(P.res) + p * P.ldres + cbase;
 #pragma unroll
             for (int a = 0; a < NCF; ++a) old[a] = *reinterpret_cast<const u32x2*>(src + a * 4);
         }
@@ -232,7 +232,7 @@ int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
                            P.Hout == P.Hg && P.Wout == P.Wg;
     if (!pointwise || !dense_out) return 0;
     if (P.Cin % 16 != 0 || P.Cin > 192 || P.Cin <= 32 || P.N % 48 != 0 || P.M % 16 != 0) return 0;
-    if (P.epi == EPI_AFFINE_ACT && P.res && P.ldres % 4 != 0) return 0;
+    if (P.res && P.ldres % 4 != 0) return 0;
     const int KS = (P.Cin + 31) / 32;
     if (KS * 32 > P.Kp) return 0;
     // channel chunk per workgroup: 96 when it divides N, else 48

@@ -3,6 +3,7 @@
 // upsample, gradient plumbing and the fused clip+Adam optimizer. All HBM-bound: 16/32-byte vector
 // accesses along the channel axis of (ptr, ld) NHWC activations.
 #include "y5m_conv.h"
+#include <stdlib.h>
 
 #define EW_T 256
 template <typename T> struct Vec8 { float v[8]; };
@@ -60,48 +61,73 @@ extern "C" int y5m_pack_weights(const float* src, int Cout, int Cin, int KH, int
     return Y5M_OK;
 }
 
-// All weight packs of a step in ONE launch: a device table of jobs with element-count prefixes;
-// each thread finds its job by binary search (the table is ~200 entries, L2/scalar-cache resident).
+// All weight packs of a step in ONE launch: a device table of jobs with element-count prefixes; each
+// thread produces 8 CONSECUTIVE k of one packed row (one job search, one row/tap decomposition and one
+// 16/32-byte store per 8 gathered values; Kp and the job starts are multiples of 8).
 template <typename T>
-__device__ __forceinline__ void pack_one(const y5m_pack_job& J, int64_t i) {
-    const int r = (int)(i / J.Kp), k = (int)(i - (int64_t)r * J.Kp);
-    float v = 0.0f;
+__device__ __forceinline__ float pack_value(const y5m_pack_job& J, int r, int k) {
     if (J.mode == 2) {
         const int tap = k >> 4, cc = k & 15;
         if (r < J.Cout && tap < 9 && cc < 12) {
             const int a = tap / 3, b = tap - 3 * a;
             const int dyx = cc / 3, c = cc - 3 * dyx;
-            v = J.src[((r * J.Cin + c) * J.KH + (2 * a + (dyx >> 1))) * J.KW + (2 * b + (dyx & 1))];
+            return J.src[((r * J.Cin + c) * J.KH + (2 * a + (dyx >> 1))) * J.KW + (2 * b + (dyx & 1))];
         }
-    } else {
-        const int Cc = J.mode == 0 ? J.Cin : J.Cout;
-        const int Cs = J.cstride > 0 ? J.cstride : Cc;
-        const int R = J.mode == 0 ? J.Cout : J.Cin;
-        const int tap = k / Cs, cc = k - tap * Cs;
-        if (r < R && tap < J.th * J.tw && cc < Cc) {
-            const int ta = tap / J.tw, tb = tap - ta * J.tw;
-            const int kh = J.kh0 + ta * J.khs, kw = J.kw0 + tb * J.kws;
-            const int co = J.mode == 0 ? r : cc, ci = J.mode == 0 ? cc : r;
-            v = J.src[((co * J.Cin + ci) * J.KH + kh) * J.KW + kw];
-        }
+        return 0.0f;
     }
-    reinterpret_cast<T*>(J.dst)[i] = from_f32<T>(v);
+    const int Cc = J.mode == 0 ? J.Cin : J.Cout;
+    const int Cs = J.cstride > 0 ? J.cstride : Cc;
+    const int R = J.mode == 0 ? J.Cout : J.Cin;
+    const int tap = k / Cs, cc = k - tap * Cs;
+    if (r < R && tap < J.th * J.tw && cc < Cc) {
+        const int ta = tap / J.tw, tb = tap - ta * J.tw;
+        const int kh = J.kh0 + ta * J.khs, kw = J.kw0 + tb * J.kws;
+        const int co = J.mode == 0 ? r : cc, ci = J.mode == 0 ? cc : r;
+        return J.src[((co * J.Cin + ci) * J.KH + kh) * J.KW + kw];
+    }
+    return 0.0f;
 }
 template <typename T>
-__global__ void pack_batched_kernel(const y5m_pack_job* __restrict__ jobs, int njobs, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__global__ void pack_batched_kernel(const y5m_pack_job* __restrict__ jobs, int njobs, int64_t total8) {
+    const int64_t i8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i8 >= total8) return;
+    const int64_t i = i8 * 8;
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
     }
-    pack_one<T>(jobs[lo], i - jobs[lo].start);
+    const y5m_pack_job J = jobs[lo];
+    const int64_t e = i - J.start;
+    const int r = (int)(e / J.Kp), k0 = (int)(e - (int64_t)r * J.Kp);
+    float v[8];
+    const int Cc = J.mode == 0 ? J.Cin : J.Cout;
+    const int Cs = J.cstride > 0 ? J.cstride : Cc;
+    const int tap = J.mode == 2 ? 0 : k0 / Cs, cc0 = k0 - tap * Cs;
+    if (J.mode != 2 && cc0 + 8 <= Cs) {
+        // the 8 values share one tap: one decomposition, a constant source stride
+        const int R = J.mode == 0 ? J.Cout : J.Cin;
+        const bool ok = r < R && tap < J.th * J.tw;
+        const int ta = tap / J.tw, tb = tap - ta * J.tw;
+        const int kh = J.kh0 + ta * J.khs, kw = J.kw0 + tb * J.kws;
+        const int64_t tapoff = (int64_t)kh * J.KW + kw;
+        const int64_t khw = (int64_t)J.KH * J.KW;
+        // mode 0: src[((r*Cin + cc)*KH + kh)*KW + kw] ; mode 1: src[((cc*Cin + r)*KH + kh)*KW + kw]
+        const int64_t base = J.mode == 0 ? (int64_t)r * J.Cin * khw + tapoff : (int64_t)r * khw + tapoff;
+        const int64_t step = J.mode == 0 ? khw : (int64_t)J.Cin * khw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (ok && cc0 + j < Cc) ? J.src[base + (cc0 + j) * step] : 0.0f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pack_value<T>(J, r, k0 + j);
+    }
+    store8<T>(reinterpret_cast<T*>(J.dst) + e, v);
 }
 extern "C" int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t total, int dtype, void* stream) {
     if (njobs <= 0 || total <= 0) return Y5M_OK;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(ew_blocks(total)), dim3(EW_T), 0, y5m_stream(stream),
-                                         d_jobs, njobs, total);)
+    Y5M_REQUIRE(total % 8 == 0, "packed sizes must be multiples of 8 elements");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(ew_blocks(total / 8)), dim3(EW_T), 0, y5m_stream(stream),
+                                         d_jobs, njobs, total / 8);)
     Y5M_CHECK_LAUNCH("pack_batched_kernel");
     return Y5M_OK;
 }
@@ -327,7 +353,10 @@ extern "C" int y5m_bn_fold(const float* gamma, const float* beta, const float* r
 // stride: a thread keeps ITS chunk's per-channel coefficients in registers for the whole kernel (they were
 // re-loaded per pixel before: 6 parameter vectors per 2 data vectors) and has U independent rows in flight.
 struct EwGeom { int CG, groups, RP; unsigned gx; };
+static int g_ew_gx = -1;
 static inline EwGeom ew_geom(int64_t M, int C8, int max_gx) {
+    if (g_ew_gx < 0) { const char* e = getenv("Y5M_EW_GX"); g_ew_gx = e ? atoi(e) : 0; }
+    if (g_ew_gx > 0 && max_gx > 512) max_gx = g_ew_gx;
     EwGeom g;
     g.CG = 1;
     for (int d = C8 < 32 ? C8 : 32; d >= 1; --d) if (C8 % d == 0) { g.CG = d; break; }

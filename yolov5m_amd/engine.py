@@ -46,6 +46,7 @@ class Act:
         self.off = off
         self.grad = None          # Act over the gradient buffer (training)
         self.gw = False           # plan-time flag: gradient already written in this backward pass
+        self.lazy = None          # plan-time: a gradient (Act) still to be added into .grad (see Engine._flush_lazy)
         self.children = []        # channel slices of a concat buffer
 
     @property
@@ -93,6 +94,7 @@ class Engine:
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
+        self.lazy_residual = os.environ.get("Y5M_LAZY_RES", "1") != "0"
         self._bwd_stack = []
         self.layers = []
         self._scratch_elems = 0
@@ -243,6 +245,7 @@ class Engine:
             ops = []
             z = lay.z
             dz = z.grad
+            ops.extend(self._flush_lazy(z))           # (a pending residual copy nobody fused: make it now)
             bn = lay.bn
             slot = self._next_slot()
             scratch = self.scratch2[slot]
@@ -252,8 +255,15 @@ class Engine:
                 acc = 1 if lay.res.gw else 0
                 lay.res.gw = True
                 rg = lay.res.grad
-                ops.append((lambda rg=rg, dz=dz, acc=acc: _lib.check(
-                    L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), ()))
+                if acc == 0 and self.lazy_residual:
+                    # first writer of d(res): a plain copy of dz. Do not make it -- the next writer (the data
+                    # gradient of the bottleneck's first conv) reads dz as its accumulation source instead:
+                    # d(res) = dz + dgrad, one pass less over the tensor (see _flush_lazy for every other writer)
+                    lay.res.lazy = dz
+                else:
+                    ops.extend(self._flush_lazy(lay.res))
+                    ops.append((lambda rg=rg, dz=dz, acc=acc: _lib.check(
+                        L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), ()))
             # BN + SiLU backward -> dy (scratch), dgamma, dbeta
             ops.append((lambda: _lib.check(
                 L.y5m_bn_bwd(dz.ptr, dz.ld, _lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
@@ -287,6 +297,8 @@ class Engine:
                 lay.x.gw = True
                 for c in lay.x.children:
                     c.gw = True
+                lazy = lay.x.lazy                    # pending residual gradient: fused as the accumulation source
+                lay.x.lazy = None
                 lay.dgrad_args = []
                 dyA = Act(scratch, lay.x.B, lay.Ho, lay.Wo, lay.cout)
                 for (wd, py, px, tht, kh0, khs, dh0, kw0, kws, dw0) in lay.wd:
@@ -305,11 +317,25 @@ class Engine:
                     a.N, a.M = lay.x.C, lay.x.B * a.Hg * a.Wg
                     a.Hout, a.Wout, a.ldout = lay.x.H, lay.x.W, xg.ld
                     a.epi, a.act, a.accumulate = EPI_DGRAD, ACT_NONE, acc
+                    if lazy is not None:
+                        assert acc == 1
+                        a.res, a.ldres = lazy.ptr, lazy.ld
                     a.Np = wd.shape[0]
                     lay.dgrad_args.append(a)
                     ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm"), ()))
             return ops
         self._bwd_stack.append(backward)
+
+    def _flush_lazy(self, act):
+        """ops that materialise a pending lazy gradient of `act` (grad = lazy source): a copy. Called by every
+        gradient writer / reader that cannot take the source as a fused accumulation operand."""
+        if act is None or act.lazy is None:
+            return []
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        src, g = act.lazy, act.grad
+        act.lazy = None
+        return [(lambda: _lib.check(L.y5m_add(src.ptr, src.ld, g.ptr, g.ld, act.B * act.H * act.W, act.C, 0, dt, st()),
+                                    "y5m_add(lazy)"), ())]
 
     def _c3(self, name, x, cout, width, depth, backbone, dest=None):
         """reference model.py:54-92"""
@@ -362,9 +388,10 @@ class Engine:
                                             "y5m_upsample2x"), ()))
         if self.training:
             def backward():
+                pre = self._flush_lazy(x)
                 acc = 1 if x.gw else 0
                 x.gw = True
-                return [(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
+                return pre + [(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
                                                                  x.grad.ptr, x.grad.ld, acc, dt, st()),
                                             "y5m_upsample2x_bwd"), ())]
             self._bwd_stack.append(backward)

@@ -107,9 +107,10 @@ def conv_forward_stats(x, w, stride, pad, dtype="f32"):
     return from_nhwc(out), s[0, :Cout], s[1, :Cout]
 
 
-def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None):
+def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None):
     """dy (B,Cout,Ho,Wo), w (Cout,Cin,k,k) -> dx (B,Cin,H,W): autograd of conv2d wrt its input.
-    init (B,Cin,H,W): accumulate the gradient onto it (the engine's fan-out accumulation; stride 1 only)."""
+    init (B,Cin,H,W): accumulate the gradient onto it (the engine's fan-out accumulation; stride 1 only).
+    src  (B,Cin,H,W): dx = src + gradient with src read from its OWN tensor (the fused residual gradient)."""
     L = _lib.lib()
     dt, tdt, CH, BK = _DT[dtype]
     B, Cout, Ho, Wo = dy.shape
@@ -118,6 +119,9 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None):
     dyn = to_nhwc(dy, tdt)
     dx = torch.zeros((B, H, W, Cin), dtype=tdt, device=dy.device) if init is None else to_nhwc(init, tdt)
     assert init is None or stride == 1
+    srcn = to_nhwc(src, tdt) if src is not None else None
+    if src is not None:
+        dx.fill_(7.0)                # must be overwritten, not accumulated
     wsrc = w.contiguous().float()
     classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(2) for px in range(2)]
     for (py, px) in classes:
@@ -145,7 +149,9 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None):
         a.Cin, a.K, a.Kp, a.N, a.M = Cout, Kd, wd.shape[1], Cin, B * a.Hg * a.Wg
         a.Hout, a.Wout, a.ldout = H, W, Cin
         a.epi, a.Np = EPI_DGRAD, wd.shape[0]
-        a.accumulate = 0 if init is None else 1
+        a.accumulate = 0 if (init is None and src is None) else 1
+        if srcn is not None:
+            a.res, a.ldres = srcn.data_ptr(), Cin
         _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv(dgrad)")
         torch.cuda.synchronize()
     return from_nhwc(dx)
