@@ -196,6 +196,8 @@ typedef struct {
     const float* src;
     void* dst;
     int32_t Cout, Cin, KH, KW, mode, kh0, khs, th, kw0, kws, tw, rows_p, Kp, cstride;
+    int32_t ldd;         /* dst row pitch in elements (0 = Kp): a job may fill a column window of wider rows */
+    int32_t pad_;
     int64_t start;
 } y5m_pack_job;
 int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t total, int dtype, void* stream);

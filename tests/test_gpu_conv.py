@@ -201,6 +201,8 @@ BN_CASES = [
     (777, 384, 768),
     (300, 768, 768),
     (70000, 48, 48),
+    (400000, 48, 48),       # more pixel rows than the grid covers in one pass: the unrolled grid-stride loops
+    (250000, 96, 192),
 ]
 
 
@@ -300,3 +302,33 @@ def test_bn_act_and_backward(case, dtype):
         assert _relerr(dy.float().cpu(), yc.grad.float()) < tol
         assert _relerr(dg.cpu(), g64.grad.float()) < 2e-4
         assert _relerr(db.cpu(), b64.grad.float()) < 2e-4
+
+
+def test_bn_shared_workspace_across_widths():
+    """the engine shares ONE BatchNorm workspace between layers of different widths: wide layer, narrow
+    layer, wide layer again through the same buffer must all come out right (the ticket counters may not live
+    where another width keeps its stage rows)"""
+    from yolov5m_amd import _lib
+    L = _lib.lib()
+    wsb = max(L.y5m_bn_finalize_workspace_bytes(768), L.y5m_bn_finalize_workspace_bytes(96))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    for it, C in enumerate((768, 48, 192, 96, 768, 48)):
+        M, Np = 3000, (C + 95) // 96 * 96
+        rows = (M + 127) // 128
+        y = _rand((M, C), 81 + it, -2.0, 2.0) * (1 + it)
+        yp = torch.cat([y, torch.zeros((rows * 128 - M, C))])
+        blk = yp.view(rows, 128, C)
+        part = torch.zeros((rows, 2, Np))
+        part[:, 0, :C] = blk.sum(1)
+        part[:, 1, :C] = (blk * blk).sum(1)
+        ones, zeros = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        out = torch.zeros((4, C), device=DEV)
+        partd = part.to(DEV)
+        _lib.check(L.y5m_bn_finalize(_lib.ptr(partd), rows, Np, C, M, _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(rm), _lib.ptr(rv),
+                                     0.03, 1e-3, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                     1, _lib.ptr(ws), wsb, _lib.stream_ptr()), "bn_finalize")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out[2].cpu().numpy(), y.double().mean(0).float().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out[3].cpu().numpy(), (1.0 / torch.sqrt(y.double().var(0, unbiased=False) + 1e-3)).float().numpy(),
+                                   rtol=1e-4)

@@ -60,7 +60,7 @@ class PackJob(ctypes.Structure):
     """mirror of y5m_pack_job (include/y5m.h)"""
     _fields_ = ([("src", c_void_p), ("dst", c_void_p)] +
                 [(n, c_int) for n in ("Cout", "Cin", "KH", "KW", "mode", "kh0", "khs", "th", "kw0", "kws", "tw",
-                                      "rows_p", "Kp", "cstride")] + [("start", c_int64)])
+                                      "rows_p", "Kp", "cstride", "ldd", "pad_")] + [("start", c_int64)])
 
 
 EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD, EPI_DGRAD = 0, 1, 2, 3

@@ -121,7 +121,7 @@ __global__ void pack_batched_kernel(const y5m_pack_job* __restrict__ jobs, int n
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = pack_value<T>(J, r, k0 + j);
     }
-    store8<T>(reinterpret_cast<T*>(J.dst) + e, v);
+    store8<T>(reinterpret_cast<T*>(J.dst) + (J.ldd > 0 ? (int64_t)r * J.ldd + k0 : e), v);
 }
 extern "C" int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t total, int dtype, void* stream) {
     if (njobs <= 0 || total <= 0) return Y5M_OK;
@@ -308,9 +308,12 @@ static inline int bn_splits(int64_t R) {
     return (int)(s < 1 ? 1 : (s > BN_SPLITS ? BN_SPLITS : s));
 }
 static inline size_t bn_stage_bytes(int C) { return y5m_align((size_t)BN_SPLITS * 2 * (size_t)C * sizeof(float)); }
-static inline size_t bn_ctr_bytes(int C) { return y5m_align(((size_t)C / 64 + 2) * sizeof(unsigned)); }
+// The ticket counters live at the START of a workspace, at a FIXED offset and size: one workspace is shared
+// by layers of different widths, and a counter at a width-dependent offset would sit inside another layer's
+// stage rows (garbage instead of the zero the protocol needs).
+#define BN_CTR_BYTES 1024      /* 256 counters = 16384 channels */
 
-extern "C" size_t y5m_bn_finalize_workspace_bytes(int Np) { return bn_stage_bytes(Np) + bn_ctr_bytes(Np); }
+extern "C" size_t y5m_bn_finalize_workspace_bytes(int Np) { return BN_CTR_BYTES + bn_stage_bytes(Np); }
 
 // ws: zero-filled by the caller before its FIRST use (ticket counters; every call leaves them zero); one
 // call at a time per workspace.
@@ -321,8 +324,9 @@ extern "C" int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, i
     if (ws_bytes < y5m_bn_finalize_workspace_bytes(Np)) { y5m_set_error("bn_finalize ws too small"); return Y5M_EWS; }
     Y5M_REQUIRE(C <= Np, "C <= Np");
     hipStream_t st = y5m_stream(stream);
-    float* stage = reinterpret_cast<float*>(ws);
-    unsigned* ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + bn_stage_bytes(Np));
+    Y5M_REQUIRE(C <= 16384, "C too large for the ticket counters");
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws);
+    float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + BN_CTR_BYTES);
     BnFinArgs F{(double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, update_running};
     BnBwdFinArgs G{};
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<0>, dim3((unsigned)bn_splits(tiles_m), (unsigned)((C + 63) / 64)), dim3(1024), 0,
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 #define BNR_MAX_GX 512     // partial rows of the backward reduce (gx * groups <= 512 blocks: 2 per CU)
 extern "C" size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C) {
-    return y5m_align((size_t)BNR_MAX_GX * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + bn_stage_bytes(C) + bn_ctr_bytes(C);
+    return BN_CTR_BYTES + y5m_align((size_t)BNR_MAX_GX * 2 * (size_t)C * 4) + y5m_align((size_t)2 * C * 4) + bn_stage_bytes(C);
 }
 
 // Full BN+SiLU backward of one CBL: param grads (dgamma, dbeta: accumulate flag) and dy.
@@ -556,13 +560,15 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
                           int dtype, void* stream) {
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     if (ws_bytes < y5m_bn_bwd_workspace_bytes(M, C)) { y5m_set_error("bn_bwd ws too small"); return Y5M_EWS; }
+    Y5M_REQUIRE(C <= 16384, "C too large for the ticket counters");
     char* w = reinterpret_cast<char*>(ws);
+    unsigned* ctr = reinterpret_cast<unsigned*>(w);             // fixed place: see BN_CTR_BYTES
+    w += BN_CTR_BYTES;
     float* part = reinterpret_cast<float*>(w);
     w += y5m_align((size_t)BNR_MAX_GX * 2 * C * 4);
     float* cB = reinterpret_cast<float*>(w), *cD = cB + C;
     w += y5m_align((size_t)2 * C * 4);
     float* stage = reinterpret_cast<float*>(w);
-    unsigned* ctr = reinterpret_cast<unsigned*>(w + bn_stage_bytes(C));
     hipStream_t st = y5m_stream(stream);
     const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(256), 0, st,

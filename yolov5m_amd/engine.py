@@ -95,6 +95,7 @@ class Engine:
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
         self.lazy_residual = os.environ.get("Y5M_LAZY_RES", "1") != "0"
+        self.merge_c3 = os.environ.get("Y5M_MERGE_C3", "1") != "0"          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
         self._bwd_stack = []
         self.layers = []
         self._scratch_elems = 0
@@ -342,7 +343,8 @@ class Engine:
         c_ = int(width * x.C)
         cat = self._new_act(x.B, x.H, x.W, 2 * c_)
         s0, s1 = cat.slice(0, c_), cat.slice(c_, c_)
-        t = self._cbl(f"{name}.c1", x, c_, 1, 1, 0)
+        merged = self.training and self.merge_c3
+        t = self._cbl_pair(f"{name}.c1", f"{name}.c_skipped", x, c_, s1) if merged else self._cbl(f"{name}.c1", x, c_, 1, 1, 0)
         for d in range(depth):
             last = d == depth - 1
             if backbone:
@@ -351,8 +353,123 @@ class Engine:
             else:
                 u = self._cbl(f"{name}.seq.{d}.0", t, c_, 1, 1, 0)
                 t = self._cbl(f"{name}.seq.{d}.1", u, c_, 3, 1, 1, dest=s0 if last else None)
-        self._cbl(f"{name}.c_skipped", x, c_, 1, 1, 0, dest=s1)
+        if not merged:
+            self._cbl(f"{name}.c_skipped", x, c_, 1, 1, 0, dest=s1)
         return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0, dest=dest)
+
+    def _cbl_pair(self, nameA, nameB, x, cout, destB):
+        """C3's two 1x1 CBLs on the SAME input (reference model.py:69 c1 and :77 c_skipped) as ONE GEMM with
+        N = 2*cout: x is read once by the forward conv and once by the weight gradient, and the data gradient
+        is one K = 2*cout GEMM that writes dx once (instead of a second read-modify-write pass). BatchNorm
+        statistics, parameters, activations and gradients stay per layer: the two halves of the merged raw
+        output / dy buffers are (ptr, ld) views. Training mode only (eval folds BN into two plain convs)."""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        esz = 2 if self.tdt == torch.bfloat16 else 4
+        N2, M, K = 2 * cout, x.B * x.H * x.W, x.C
+        Kp = _rup(K, self.BK)
+        Np2 = _rup(N2, L.y5m_conv_tile_n(N2))
+        destA = self._new_act(x.B, x.H, x.W, cout)
+        wf = torch.zeros((Np2, Kp), dtype=self.tdt, device=self.dev)
+        y2 = torch.zeros((M * N2,), dtype=self.tdt, device=self.dev)
+        tiles_m = (M + 127) // 128
+        self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np2)
+        halves = []
+        for name, off, dest in ((nameA, 0, destA), (nameB, cout, destB)):
+            P = self.model.pslices[name]
+            lay = _Layer()
+            lay.name, lay.x, lay.res, lay.stem = name, x, None, False
+            lay.cin_real, lay.cout, lay.k, lay.s, lay.p = x.C, cout, 1, 1, 0
+            lay.kk, lay.ss, lay.pp, lay.M, lay.Ho, lay.Wo = 1, 1, 0, M, x.H, x.W
+            lay.z, lay.off = dest, off
+            lay.bn = torch.zeros((4, cout), dtype=torch.float32, device=self.dev)
+            rows = cout if off == 0 else Np2 - cout          # the second job also zero-fills the row padding
+            self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, x.C, 1, 1, 0, 0, 1, 1, 0, 1, 1,
+                       ctypes.c_void_p(wf.data_ptr() + off * Kp * esz), rows, Kp, 0, dt)
+            halves.append((lay, P))
+            self.layers.append(lay)
+        halves[0][0].pair_buffers = (wf, y2)             # the launch descriptors hold raw pointers: keep the tensors alive
+        a = self._conv_args(x, wf, y2.data_ptr(), x.H, x.W, 1, 1, 0, N2, N2, EPI_RAW_STATS, Kp)
+        halves[0][0].fwd_args = a
+        self._stat_users.append(a)
+        self._run_conv(self.fwd, a)
+        for lay, P in halves:
+            def finalize(lay=lay, P=P):
+                bn = lay.bn
+                _lib.check(L.y5m_bn_finalize(self.stats.data_ptr() + 4 * lay.off, tiles_m, Np2, cout, M, _lib.ptr(P["g"]),
+                                             _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]), BN_MOMENTUM, BN_EPS,
+                                             bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(), bn[3].data_ptr(), 1,
+                                             _lib.ptr(self.finws), self.finws.numel(), st()), "y5m_bn_finalize")
+            self.fwd.append((finalize, ()))
+
+            def apply(lay=lay):
+                bn = lay.bn
+                _lib.check(L.y5m_bn_act(y2.data_ptr() + lay.off * esz, N2, bn[0].data_ptr(), bn[1].data_ptr(), None, 0,
+                                        lay.z.ptr, lay.z.ld, M, cout, ACT_SILU, dt, st()), "y5m_bn_act")
+            self.fwd.append((apply, ()))
+        # ---- backward: pushed at c1's place, i.e. executed after the whole C3 body, when both dz are final
+        self._scratch_elems = max(self._scratch_elems, M * N2)
+        self._bnws_bytes = max(self._bnws_bytes, L.y5m_bn_bwd_workspace_bytes(M, cout))
+        gw_off = self._gw_floats
+        self._gw_floats += N2 * K
+        need_dx = x.grad is not None
+        wd = None
+        if need_dx:
+            wd = torch.zeros((_rup(K, L.y5m_conv_tile_n(K)), _rup(N2, self.BK)), dtype=self.tdt, device=self.dev)
+            halves[1][0].pair_buffers = (wd,)
+            for lay, P in halves:
+                cols = cout if lay.off == 0 else wd.shape[1] - cout
+                self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, K, 1, 1, 1, 0, 1, 1, 0, 1, 1,
+                           ctypes.c_void_p(wd.data_ptr() + lay.off * esz), wd.shape[0], cols, 0, dt, wd.shape[1])
+
+        def backward():
+            ops = []
+            slot = self._next_slot()
+            scratch = self.scratch2[slot]
+            ops.append((self._join_op(slot), ()))
+            for lay, P in halves:
+                ops.extend(self._flush_lazy(lay.z))
+                dz, bn = lay.z.grad, lay.bn
+                ops.append((lambda lay=lay, P=P, dz=dz, bn=bn: _lib.check(
+                    L.y5m_bn_bwd(dz.ptr, dz.ld, y2.data_ptr() + lay.off * esz, N2, bn[0].data_ptr(), bn[1].data_ptr(),
+                                 bn[2].data_ptr(), bn[3].data_ptr(), M, cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]),
+                                 0, scratch.data_ptr() + lay.off * esz, N2, _lib.ptr(self.bnws), self._bnws_bytes, dt,
+                                 st()), "y5m_bn_bwd"), ()))
+            wa = WgradArgs()
+            wa.zeros = _lib.zero_page(self.dev).data_ptr()
+            wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * gw_off
+            wa.B, wa.Hin, wa.Win, wa.ldx = x.B, x.H, x.W, x.ld
+            wa.Hg, wa.Wg, wa.sy, wa.sx = x.H, x.W, 1, 1
+            wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
+            wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = K, N2, M, N2, K, 0
+            fs = [lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(pair)")]
+            for lay, P in halves:
+                fs.append(lambda lay=lay, P=P: _lib.check(
+                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * (gw_off + lay.off * K), cout, K, 1, 1, 0, K,
+                                       _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(pair)"))
+            ops.append((self._side_op(fs, slot), ()))
+            for lay, P in halves:
+                self._grad_done.append((lay.name, P["gw"].data_ptr()))
+            if need_dx:
+                pre = self._flush_lazy(x)
+                ops.extend(pre)
+                acc = 1 if x.gw else 0
+                x.gw = True
+                for c in x.children:
+                    c.gw = True
+                g = ConvArgs()
+                g.zeros = _lib.zero_page(self.dev).data_ptr()
+                g.inp, g.w, g.out = scratch.data_ptr(), wd.data_ptr(), x.grad.ptr
+                g.B, g.Hin, g.Win, g.ldin = x.B, x.H, x.W, N2
+                g.Hg, g.Wg, g.sy, g.sx = x.H, x.W, 1, 1
+                g.th, g.tw, g.dh0, g.dhs, g.dw0, g.dws = 1, 1, 0, -1, 0, -1
+                g.Cin, g.K, g.Kp, g.N, g.M = N2, N2, wd.shape[1], K, M
+                g.Hout, g.Wout, g.ldout, g.osy, g.osx, g.ooy, g.oox = x.H, x.W, x.grad.ld, 1, 1, 0, 0
+                g.epi, g.act, g.accumulate, g.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
+                ops.append((_kind(lambda g=g: _lib.check(L.y5m_conv(ctypes.byref(g), dt, st()), "y5m_conv(pair dgrad)"),
+                                  "conv_igemm"), ()))
+            return ops
+        self._bwd_stack.append(backward)
+        return destA
 
     def _sppf(self, name, x, cout):
         """reference model.py:96-112"""
@@ -584,7 +701,8 @@ class Engine:
             if fn is L.y5m_pack_weights:
                 j = _lib.PackJob()
                 (src, j.Cout, j.Cin, j.KH, j.KW, j.mode, j.kh0, j.khs, j.th, j.kw0, j.kws, j.tw, dst, j.rows_p, j.Kp,
-                 j.cstride, _dt) = args
+                 j.cstride, _dt) = args[:17]
+                j.ldd = args[17] if len(args) > 17 else 0       # (engine-only extension: column window of wider rows)
                 j.src, j.dst, j.start = src.value, dst.value, total
                 total += j.rows_p * j.Kp
                 jobs.append(j)
