@@ -303,8 +303,30 @@ def g6_decode_nms(model):
     save("g6_decode_nms", **out)
 
 
+def g7_large_step(model):
+    """first train-mode forward + ComputeLoss of the reference at a batch large enough that every layer width
+    runs its multi-workgroup reductions (B=16 @ 320x320): the loss and its 3 components, and sampled logits"""
+    sd = synth_state_dict()
+    B, S = 16, 320
+    model.load_state_dict(sd, strict=True)
+    model.train(True)
+    x = synth_images(B, S, S, seed="img/rank0")
+    t = synth_labels(B, 8, seed="lab/rank0")
+    lf = R.ComputeLoss(model)
+    with torch.no_grad():
+        o = model(x.clone())
+        loss = lf(o, t, None)
+    out = {"loss": np.array(float(loss)), "targets": t.numpy(), "shape": np.array([B, S, S])}
+    for i in range(3):
+        flat = o[i].reshape(-1).numpy()
+        step = max(1, flat.size // 4096)
+        out[f"o{i}_sample"] = flat[::step][:4096].copy()
+        out[f"o{i}_step"] = np.array(step)
+    save("g7_large_step", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -313,3 +335,4 @@ if __name__ == "__main__":
     if "g4" in which: g4_yolo_loss(model)
     if "g6" in which: g6_decode_nms(model)
     if "g5" in which: g5_model(model)
+    if "g7" in which: g7_large_step(model)

@@ -178,6 +178,7 @@ class NativeTrainStep:
                 with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._optimizer()
                 self._graph, self._key = (g1, g2), key
+                return self.loss_out                     # this call WAS the eager step: one call = one step
             except Exception as e:                       # capture is an optimisation, never a requirement
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
