@@ -78,8 +78,15 @@ def test_forward_bf16_vs_oracle(mode):
         assert err < 3.0 * floor + 0.03, (mode, err, floor)
 
 
-def test_train_step_grads_f32_golden(golden):
+@pytest.mark.parametrize("variant", ["default", "bnred_all", "unfused"])
+def test_train_step_grads_f32_golden(golden, variant, monkeypatch):
+    """default engine plan; every optional graph-level fusion ON (BatchNorm-backward reduction fused into the
+    last data gradient of every eligible layer); every one OFF (no merged C3 pair, no lazy residual)"""
     from yolov5m_amd.ultralytics_loss import ComputeLoss
+    if variant == "bnred_all":
+        monkeypatch.setenv("Y5M_BNRED", "all")
+    elif variant == "unfused":
+        monkeypatch.setenv("Y5M_MERGE_C3", "0"); monkeypatch.setenv("Y5M_LAZY_RES", "0"); monkeypatch.setenv("Y5M_OVERLAP", "0")
     g = golden("g5_model")
     m = _model("f32")
     m.train()
@@ -161,12 +168,13 @@ def test_large_batch_first_step_golden(golden):
     np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-4)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_large_batch_native_steps_bf16(golden, use_graph):
+@pytest.mark.parametrize("use_graph,bnred", [(False, "0"), (True, "0"), (True, "1"), (True, "all")])
+def test_large_batch_native_steps_bf16(golden, use_graph, bnred, monkeypatch):
     """the fused native step at B=16 @ 320x320, bf16, eager and hipGraph replay: first loss close to the
     reference's (bf16 activations: 2 %), finite and decreasing afterwards, parameters finite"""
     from yolov5m_amd.ultralytics_loss import ComputeLoss
     from yolov5m_amd.utils.training_utils import NativeTrainStep
+    monkeypatch.setenv("Y5M_BNRED", bnred)
     g = golden("g7_large_step")
     B, H, W = [int(v) for v in g["shape"]]
     x = synth_images(B, H, W, seed="img/rank0").to(DEV)

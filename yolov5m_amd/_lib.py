@@ -33,7 +33,10 @@ class ConvArgs(ctypes.Structure):
                                       "osx", "ooy", "oox", "epi", "act", "accumulate")] +
                 [("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("ldres", c_int),
                  ("stats", c_void_p), ("Np", c_int), ("naxs", c_int), ("nch", c_int), ("tiles_m", c_int),
-                 ("tiles_n", c_int), ("zeros", c_void_p)])
+                 ("tiles_n", c_int), ("zeros", c_void_p),
+                 ("bn_y", c_void_p), ("bn_y2", c_void_p), ("bn_scale", c_void_p), ("bn_shift", c_void_p),
+                 ("bn_scale2", c_void_p), ("bn_shift2", c_void_p), ("bn_part", c_void_p),
+                 ("bn_ldy", c_int), ("bn_ldy2", c_int), ("bn_split", c_int), ("bn_pad_", c_int)])
 
 
 class WgradArgs(ctypes.Structure):
@@ -94,6 +97,7 @@ _SIGS = {
                                        c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
                                        c_size_t, c_void_p]),
     "y5m_conv_tile_n": (c_int, [c_int]),
+    "y5m_conv_is_pointwise": (c_int, [c_void_p, c_int]),
     "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -111,6 +115,9 @@ _SIGS = {
     "y5m_bn_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                            c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int,
                            c_void_p]),
+    "y5m_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                         c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "y5m_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "y5m_upsample2x": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_upsample2x_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,

@@ -79,3 +79,7 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad(float t) {
+    const float s = 1.0f / (1.0f + __expf(-t));
+    return s * (1.0f + t * (1.0f - s));
+}

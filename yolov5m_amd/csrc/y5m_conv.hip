@@ -8,7 +8,9 @@
 // DB = true : two LDS buffers, one barrier per K step (long K: MFMA-bound layers)
 // DB = false: one LDS buffer, two barriers per K step, half the LDS -> more resident workgroups per CU
 //             (short K, e.g. 1x1 convs with C <= 384: latency/HBM-bound, TLP hides the load latency)
-template <typename T, int WM, int WN, int MF, int NF, bool DB>
+// BNR  = true : data-gradient launch that is the LAST writer of a CBL output gradient: the epilogue also emits
+//             the BatchNorm-backward reduction partials (y5m_conv_args.bn_part), see include/y5m.h
+template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams P) {
     constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -225,6 +227,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     // dense output (no strided scatter): output pixel index == m, skip the decomposition
     const bool lin_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
                          P.Hout == P.Hg && P.Wout == P.Wg;
+    float bs1[BNR ? NF : 1][4], bs2[BNR ? NF : 1][4];          // BNR: per-lane (sum dt, sum dt*y) over the MF pixel fragments
+    if constexpr (BNR) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bs1[a][r] = 0.f; bs2[a][r] = 0.f; }
+    }
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
         const int m = mb + b * 16;
@@ -279,17 +288,69 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
                 for (int r = 0; r < 4; ++r) v[r] += ov[r];
             }
             store4<T>(o, v);
+            if constexpr (BNR) {
+                // dz as the standalone reduce pass would read it back (rounded to T), y of the producer
+                const bool second = n >= P.bn_split;
+                const float* scp = second ? P.bn_scale2 : P.bn_scale;
+                if (scp) {
+                    const int nn = second ? n - P.bn_split : n;
+                    const T* yp = second ? reinterpret_cast<const T*>(P.bn_y2) + opix * P.bn_ldy2 + nn
+                                         : reinterpret_cast<const T*>(P.bn_y) + opix * P.bn_ldy + nn;
+                    const float* shp = (second ? P.bn_shift2 : P.bn_shift) + nn;
+                    float yv[4];
+                    load4<T>(yp, yv);
+                    const float4 sc = *reinterpret_cast<const float4*>(scp + nn);
+                    const float4 sh = *reinterpret_cast<const float4*>(shp);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dzr = to_f32<T>(from_f32<T>(v[r]));
+                        const float dt = dzr * silu_grad(yv[r] * scv[r] + shv[r]);
+                        bs1[a][r] += dt;
+                        bs2[a][r] += dt * yv[r];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (BNR) {
+        // lanes (16 pixels) -> wave -> the WM waves of the tile, as the RAW_STATS partials
+        __syncthreads();                                       // every wave is past its last LDS tile read
+        float* red = reinterpret_cast<float*>(smem);          // [2][WM][BN]
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { bs1[a][r] += __shfl_xor(bs1[a][r], o, 64); bs2[a][r] += __shfl_xor(bs2[a][r], o, 64); }
+            }
+            if (frow == 0) {
+                const int nl = wn * NF * 16 + a * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(0 * WM + wm) * BN + nl + r] = bs1[a][r];
+                    red[(1 * WM + wm) * BN + nl + r] = bs2[a][r];
+                }
+            }
+        }
+        __syncthreads();
+        for (int tt = tid; tt < 2 * BN; tt += CV_THREADS) {
+            const int which = tt / BN, nl = tt - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + nl];
+            if (n0 + nl < P.Np) P.bn_part[((size_t)tile_m * 2 + which) * P.Np + n0 + nl] = t;
         }
     }
 }
 
-template <typename T, int WM, int WN, int MF, int NF, bool DB>
+template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR = false>
 static int launch_conv_db(ConvParams& P, hipStream_t st) {
     constexpr int BN = WN * NF * 16;
     P.tiles_m = (P.M + CV_BM - 1) / CV_BM;
     P.tiles_n = (P.N + BN - 1) / BN;
     const size_t lds = (DB ? 2 : 1) * (size_t)(CV_BM + BN) * 128;
-    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, DB>;
+    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, DB, BNR>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -308,6 +369,13 @@ template <typename T, int WM, int WN, int MF, int NF>
 static int launch_conv(ConvParams& P, hipStream_t st) {
     if (g_sbuf_kt < 0) { const char* e = getenv("Y5M_CONV_SBUF_KT"); g_sbuf_kt = e ? atoi(e) : 6; }
     const int BK = sizeof(T) == 2 ? 64 : 32;
+    if constexpr (NF <= 3) {
+        // (the 192-channel tile has no register room for the 2 x NF x 4 per-lane partials: see conv_dispatch)
+        if (P.epi == EPI_DGRAD && P.bn_part) {
+            if (P.Kp / BK <= g_sbuf_kt) return launch_conv_db<T, WM, WN, MF, NF, false, true>(P, st);
+            return launch_conv_db<T, WM, WN, MF, NF, true, true>(P, st);
+        }
+    }
     if (P.Kp / BK <= g_sbuf_kt) return launch_conv_db<T, WM, WN, MF, NF, false>(P, st);
     return launch_conv_db<T, WM, WN, MF, NF, true>(P, st);
 }
@@ -327,7 +395,8 @@ static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
         const int r = y5m_conv_pw_try(P, dtype, st);
         if (r != 0) return r < 0 ? r : Y5M_OK;
     }
-    const int BN = y5m_conv_tile_n(P.N);
+    int BN = y5m_conv_tile_n(P.N);
+    if (P.epi == EPI_DGRAD && P.bn_part && BN == 192) BN = 96;     // fused BN-backward partials: 96-channel tile
     if (dtype == Y5M_BF16) {
         if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
         if (BN == 192) return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
@@ -353,6 +422,13 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     const int BN = y5m_conv_tile_n(P.N);
     Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
     Y5M_REQUIRE(P.Np >= (P.N + BN - 1) / BN * BN, "Np (rows of the packed weights) must cover the channel tiles");
+    if (P.bn_part) {
+        const bool dense_out = P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 && P.Hout == P.Hg && P.Wout == P.Wg;
+        Y5M_REQUIRE(P.epi == EPI_DGRAD && dense_out, "bn_part: dense stride-1 data-gradient launches only");
+        Y5M_REQUIRE(P.bn_split % 4 == 0 && P.bn_split > 0, "bn_split must be a positive multiple of 4");
+        Y5M_REQUIRE(!P.bn_scale || (P.bn_y && P.bn_shift), "bn_y / bn_shift missing");
+        Y5M_REQUIRE(!P.bn_scale2 || (P.bn_y2 && P.bn_shift2), "bn_y2 / bn_shift2 missing");
+    }
     hipStream_t st = y5m_stream(stream);
     // The kernels address the input view with 32-bit byte offsets (buffer resources; the top bit marks
     // "out of range"), so one launch sees at most 2 GiB of input: larger batches go in slabs of whole images.

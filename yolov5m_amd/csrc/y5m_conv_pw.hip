@@ -16,6 +16,8 @@
 //   * BatchNorm partial sums stay in registers for the whole stream and are reduced across the 16 pixel
 //     lanes and the 4 waves once at the end (one stats row per workgroup; unused rows are zeroed).
 #include "y5m_conv.h"
+#include <string.h>
+#include <stdlib.h>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -29,7 +31,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // prefetch index is clamped instead of guarded): with every load / store on the straight path the compiler
 // can count them, so the wait for the prefetched x fragments is a vmcnt(#stores issued since) and the
 // output stores of group g drain under the MFMAs of group g+1 instead of being waited for.
-template <int NCF, int KS, int EPI, bool OLD>
+// BNR: EPI_DGRAD launch that also emits the BatchNorm-backward reduction partials of the gradient it
+// finishes (y5m_conv_args.bn_part): the per-lane sums live in the same registers the forward statistics use.
+template <int NCF, int KS, int EPI, bool OLD, bool BNR>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams P, const int nchunks, const int nstreams,
                                                                const int ngroups, const int stat_rows) {
     constexpr int NC = NCF * 16;
@@ -62,8 +66,21 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
 #pragma unroll
         for (int j = 0; j < 4 * NCF; ++j) { sc[j] = P.scale[cbase + j]; sh[j] = P.shift[cbase + j]; }
     }
-    float ssum[EPI == EPI_RAW_STATS ? 4 * NCF : 1], ssq[EPI == EPI_RAW_STATS ? 4 * NCF : 1];
-    if constexpr (EPI == EPI_RAW_STATS) {
+    constexpr bool SUMS = EPI == EPI_RAW_STATS || BNR;
+    float ssum[SUMS ? 4 * NCF : 1], ssq[SUMS ? 4 * NCF : 1];
+    // BNR: this lane's 4*NCF channels belong to ONE producer (chunks never straddle bn_split, a multiple of 48)
+    const bool bn_second = BNR && cbase >= P.bn_split;
+    const int bn_c = bn_second ? cbase - P.bn_split : cbase;
+    const float* bn_scp = BNR ? (bn_second ? P.bn_scale2 : P.bn_scale) : nullptr;
+    const bf16_t* bn_yb = reinterpret_cast<const bf16_t*>(bn_second ? P.bn_y2 : P.bn_y);
+    const int bn_ld = bn_second ? P.bn_ldy2 : P.bn_ldy;
+    float bsc[BNR ? 4 * NCF : 1], bsh[BNR ? 4 * NCF : 1];
+    if constexpr (BNR) {
+        const float* shp = bn_second ? P.bn_shift2 : P.bn_shift;
+#pragma unroll
+        for (int j = 0; j < 4 * NCF; ++j) { bsc[j] = bn_scp ? bn_scp[bn_c + j] : 0.f; bsh[j] = bn_scp ? shp[bn_c + j] : 0.f; }
+    }
+    if constexpr (SUMS) {
 #pragma unroll
         for (int j = 0; j < 4 * NCF; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
     }
@@ -134,6 +151,21 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
             q.x = f32x2_to_bf16x2(v[0], v[1]);
             q.y = f32x2_to_bf16x2(v[2], v[3]);
             *reinterpret_cast<u32x2*>(o + a * 4) = q;
+            if constexpr (BNR) {
+                if (bn_scp) {
+                    const u32x2 yq = *reinterpret_cast<const u32x2*>(bn_yb + p * bn_ld + bn_c + a * 4);
+                    const float yv[4] = {__uint_as_float(yq.x << 16), __uint_as_float(yq.x & 0xffff0000u),
+                                         __uint_as_float(yq.y << 16), __uint_as_float(yq.y & 0xffff0000u)};
+                    const float dz[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                                         __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};   // as stored
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dt = dz[r] * silu_grad(yv[r] * bsc[a * 4 + r] + bsh[a * 4 + r]);
+                        ssum[a * 4 + r] += dt;
+                        ssq[a * 4 + r] += dt * yv[r];
+                    }
+                }
+            }
         }
     };
 
@@ -152,8 +184,9 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
         }
     }
 
-    if constexpr (EPI == EPI_RAW_STATS) {
-        if (P.stats) {
+    if constexpr (SUMS) {
+        float* const rows_out = BNR ? P.bn_part : P.stats;
+        if (rows_out) {
             // lanes -> wave (16 pixel lanes share a channel set), waves -> workgroup (through LDS, behind the
             // weights), one stats row per WORKGROUP: row `sblock`; rows sblock + k*gridDim-per-chunk are zero
             // padding so that the consumer (y5m_bn_finalize over stat_rows rows) needs no knowledge of the launch
@@ -177,7 +210,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
                 const float v = red[(0 * 2 + which) * NC + c] + red[(1 * 2 + which) * NC + c] +
                                 red[(2 * 2 + which) * NC + c] + red[(3 * 2 + which) * NC + c];
                 for (int row = sblock, first = 1; row < stat_rows; row += nsb, first = 0)
-                    P.stats[((size_t)row * 2 + which) * P.Np + n0 + c] = first ? v : 0.f;
+                    rows_out[((size_t)row * 2 + which) * P.Np + n0 + c] = first ? v : 0.f;
             }
         }
     }
@@ -186,7 +219,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
 static int g_pw = -1;          // Y5M_CONV_PW=0 routes every layer through the tiled kernel (A/B runs)
 static int g_pw_occ = -1;      // Y5M_CONV_PW_OCC: workgroups per CU of the persistent grid
 
-template <int NCF, int KS, int EPI, bool OLD>
+template <int NCF, int KS, int EPI, bool OLD, bool BNR = false>
 static int launch_pw(const ConvParams& P, hipStream_t st) {
     constexpr int NC = NCF * 16;
     if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 2; }
@@ -198,11 +231,11 @@ static int launch_pw(const ConvParams& P, hipStream_t st) {
     if (sblocks < 8) sblocks = 8;
     const int need = (ngroups + 3) / 4;
     if (sblocks > (need + 7) / 8 * 8) sblocks = (need + 7) / 8 * 8;
-    if (EPI == EPI_RAW_STATS && P.stats && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
+    if (((EPI == EPI_RAW_STATS && P.stats) || BNR) && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
     if (sblocks < 8) return 0;                                       // tiny problem: leave it to the tiled kernel
     const int nstreams = sblocks * 4;
-    const size_t lds = (size_t)NCF * KS * 64 * 16 + (EPI == EPI_RAW_STATS ? 4 * 2 * NC * sizeof(float) : 0);
-    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD>;
+    const size_t lds = (size_t)NCF * KS * 64 * 16 + ((EPI == EPI_RAW_STATS || BNR) ? 4 * 2 * NC * sizeof(float) : 0);
+    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, BNR>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -218,23 +251,26 @@ static int launch_pw_epi(const ConvParams& P, hipStream_t st) {
     if (P.epi == EPI_RAW_STATS) return launch_pw<NCF, KS, EPI_RAW_STATS, false>(P, st);
     if (P.epi == EPI_AFFINE_ACT)
         return P.res ? launch_pw<NCF, KS, EPI_AFFINE_ACT, true>(P, st) : launch_pw<NCF, KS, EPI_AFFINE_ACT, false>(P, st);
+    if (P.bn_part)
+        return P.accumulate ? launch_pw<NCF, KS, EPI_DGRAD, true, true>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false, true>(P, st);
     return P.accumulate ? launch_pw<NCF, KS, EPI_DGRAD, true>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false>(P, st);
 }
 
 // Returns 1 when the launch was taken by the pointwise kernel, 0 when the layer does not qualify (the
 // caller then uses the tiled kernel), < 0 on error.
+static bool pw_eligible(const ConvParams& P, int dtype);
+
+// 1 when y5m_conv would run this launch on the pointwise streaming kernel (memory-bound: epilogue VALU work
+// such as the fused BatchNorm-backward partials is free there), 0 for the tiled implicit-GEMM kernel.
+extern "C" int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype) {
+    ConvParams P;
+    memcpy(&P, args, sizeof(P));
+    return pw_eligible(P, dtype) ? 1 : 0;
+}
+
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
-    if (g_pw < 0) { const char* e = getenv("Y5M_CONV_PW"); g_pw = (e && e[0] == '0') ? 0 : 1; }
-    if (!g_pw || dtype != Y5M_BF16) return 0;
-    const bool pointwise = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 &&
-                           P.Hin == P.Hg && P.Win == P.Wg;
-    const bool dense_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
-                           P.Hout == P.Hg && P.Wout == P.Wg;
-    if (!pointwise || !dense_out) return 0;
-    if (P.Cin % 16 != 0 || P.Cin > 192 || P.Cin <= 32 || P.N % 48 != 0 || P.M % 16 != 0) return 0;
-    if (P.res && P.ldres % 4 != 0) return 0;
+    if (!pw_eligible(P, dtype)) return 0;
     const int KS = (P.Cin + 31) / 32;
-    if (KS * 32 > P.Kp) return 0;
     // channel chunk per workgroup: 96 when it divides N, else 48
     if (P.N % 96 == 0) {
         if (KS == 2) return launch_pw_epi<6, 2>(P, st);
@@ -246,4 +282,25 @@ int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
         if (KS == 6) return launch_pw_epi<3, 6>(P, st);
     }
     return 0;
+}
+
+static bool pw_eligible(const ConvParams& P, int dtype) {
+    if (g_pw < 0) { const char* e = getenv("Y5M_CONV_PW"); g_pw = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_pw || dtype != Y5M_BF16) return 0;
+    const bool pointwise = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 &&
+                           P.Hin == P.Hg && P.Win == P.Wg;
+    const bool dense_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
+                           P.Hout == P.Hg && P.Wout == P.Wg;
+    if (!pointwise || !dense_out) return 0;
+    if (P.Cin % 16 != 0 || P.Cin > 192 || P.Cin <= 32 || P.N % 48 != 0 || P.M % 16 != 0) return 0;
+    if (P.res && P.ldres % 4 != 0) return 0;
+    if (P.bn_part && (P.bn_split % 48 != 0 || P.bn_ldy % 4 != 0 || (P.bn_y2 && P.bn_ldy2 % 4 != 0))) return 0;
+    const int KS = (P.Cin + 31) / 32;
+    if (KS * 32 > P.Kp) return 0;
+    if (KS != 2 && KS != 3 && KS != 6) return 0;
+    // (tiny problems stay on the tiled kernel: launch_pw needs >= 8 stream blocks)
+    const int ngroups = (P.M + 15) / 16, stat_rows = (P.M + CV_BM - 1) / CV_BM;
+    if ((ngroups + 3) / 4 < 1) return 0;
+    if (((P.epi == EPI_RAW_STATS && P.stats) || P.bn_part) && stat_rows < 8) return 0;
+    return 1;
 }

@@ -438,10 +438,6 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
 // Three launches: (1) reduce (sum dt, sum dt*y) -> <= 512 partial rows, (2) bn_reduce_finalize_kernel<1>:
 // dgamma/dbeta and the apply coefficients cB/cD, (3) apply.
 // =================================================================================================
-__device__ __forceinline__ float silu_grad(float t) {
-    const float s = 1.0f / (1.0f + __expf(-t));
-    return s * (1.0f + t * (1.0f - s));
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
@@ -578,6 +574,33 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads};
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)bn_splits(gr.gx), (unsigned)((C + 63) / 64)), dim3(1024), 0,
                        st, part, (int)gr.gx, C, C, stage, ctr, F, G);
+    Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
+    const EwGeom ga = ew_geom(M, C / 8, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (T*)dy, lddy, M, ga.CG,
+                                         ga.RP, act);)
+    Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return Y5M_OK;
+}
+
+extern "C" int y5m_bn_bwd_from_partials(const float* part, int rows, int ldpart, const void* dz, int lddz, const void* y,
+                                        int ldy, const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
+                                        int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes, int dtype,
+                                        void* stream) {
+    Y5M_REQUIRE(C % 8 == 0 && C <= 16384, "C");
+    if (ws_bytes < y5m_bn_bwd_workspace_bytes(M, C)) { y5m_set_error("bn_bwd ws too small"); return Y5M_EWS; }
+    char* w = reinterpret_cast<char*>(ws);
+    unsigned* ctr = reinterpret_cast<unsigned*>(w);
+    w += BN_CTR_BYTES + y5m_align((size_t)BNR_MAX_GX * 2 * C * 4);
+    float* cB = reinterpret_cast<float*>(w), *cD = cB + C;
+    w += y5m_align((size_t)2 * C * 4);
+    float* stage = reinterpret_cast<float*>(w);
+    hipStream_t st = y5m_stream(stream);
+    BnFinArgs F{};
+    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads};
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)bn_splits(rows), (unsigned)((C + 63) / 64)), dim3(1024), 0,
+                       st, part, rows, ldpart, C, stage, ctr, F, G);
     Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
     const EwGeom ga = ew_geom(M, C / 8, 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,

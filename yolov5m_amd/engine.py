@@ -48,6 +48,10 @@ class Act:
         self.gw = False           # plan-time flag: gradient already written in this backward pass
         self.lazy = None          # plan-time: a gradient (Act) still to be added into .grad (see Engine._flush_lazy)
         self.children = []        # channel slices of a concat buffer
+        self.parent, self.c0 = None, 0     # the concat buffer this view is a slice of, first channel in it
+        self.n_cons = 0           # plan-time: ops whose backward writes this tensor's gradient (counted on the root)
+        self.n_written = 0        # plan-time: how many of them have been emitted so far in this backward plan
+        self.producer = None      # the CBL (_Layer with BatchNorm) whose output z this view is
 
     @property
     def M(self):
@@ -62,6 +66,7 @@ class Act:
         if self.grad is not None:
             s.grad = Act(self.grad.buf, self.B, self.H, self.W, C, self.grad.ld, self.grad.off + c0)
         self.children.append(s)
+        s.parent, s.c0 = self, c0
         return s
 
     def as_nchw_f32(self):
@@ -94,7 +99,17 @@ class Engine:
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
+        # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
+        # so it runs ahead of the side stream instead of ping-ponging with it (each cross-stream wait costs
+        # ~10-15 us of dependency latency inside a hipGraph); 0.63 GB per slot at B=64 / 640^2; measured: more than 2 slots buys nothing
+        self.nslots = max(2, int(os.environ.get("Y5M_SLOTS", "2")))
         self.lazy_residual = os.environ.get("Y5M_LAZY_RES", "1") != "0"
+        # BN-backward reduction fused into the gradient's last data-gradient launch (y5m_conv_args.bn_part):
+        # "1" pointwise launches only, "all" every eligible launch, "0" off. OFF by default -- measured at
+        # B=64 / 640^2: "all" (67 of 79 layers) conv +3.0 ms vs BN backward -2.0 ms; pointwise-only conv +1.4 vs
+        # BN -1.1: the silu' + two FMAs + y read per element that a purely HBM-bound reduce pass does for free
+        # are NOT free in a conv epilogue (the pointwise kernel turns VALU-bound). Kept as a tested option.
+        self.bnred = {"0": False, "all": "all"}.get(os.environ.get("Y5M_BNRED", "0"), True)
         self.merge_c3 = os.environ.get("Y5M_MERGE_C3", "1") != "0"          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
         self._bwd_stack = []
         self.layers = []
@@ -170,6 +185,10 @@ class Engine:
                    kk, _lib.ptr(lay.wf), Np, Kp, 0, dt)
         if self.training:
             lay.y = torch.zeros((M * cout,), dtype=self.tdt, device=self.dev)
+            lay.y_ptr, lay.y_ld = lay.y.data_ptr(), cout
+            dest.producer = lay
+            self._consume(x)
+            self._consume(res)
             tiles_m = (M + 127) // 128
             self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np)
             a = self._conv_args(x, lay.wf, lay.y.data_ptr(), Ho, Wo, kk, ss, pp, cout, cout, EPI_RAW_STATS, Kp)
@@ -256,6 +275,7 @@ class Engine:
                 acc = 1 if lay.res.gw else 0
                 lay.res.gw = True
                 rg = lay.res.grad
+                self._written(lay.res)
                 if acc == 0 and self.lazy_residual:
                     # first writer of d(res): a plain copy of dz. Do not make it -- the next writer (the data
                     # gradient of the bottleneck's first conv) reads dz as its accumulation source instead:
@@ -266,11 +286,7 @@ class Engine:
                     ops.append((lambda rg=rg, dz=dz, acc=acc: _lib.check(
                         L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), ()))
             # BN + SiLU backward -> dy (scratch), dgamma, dbeta
-            ops.append((lambda: _lib.check(
-                L.y5m_bn_bwd(dz.ptr, dz.ld, _lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
-                             bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]),
-                             _lib.ptr(P["gb"]), 0, _lib.ptr(scratch), lay.cout, _lib.ptr(self.bnws),
-                             self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ()))
+            ops.append(self._bn_backward_op(lay, P, dz, scratch.data_ptr(), lay.cout))
             # weight gradient (packed f32, atomics into the zeroed gw buffer)
             wa = WgradArgs()
             wa.zeros = _lib.zero_page(self.dev).data_ptr()
@@ -322,10 +338,80 @@ class Engine:
                         assert acc == 1
                         a.res, a.ldres = lazy.ptr, lazy.ld
                     a.Np = wd.shape[0]
+                    if lay.ss == 1:
+                        self._bnred_plan(lay.x, a)
                     lay.dgrad_args.append(a)
                     ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm"), ()))
+                self._written(lay.x)
             return ops
         self._bwd_stack.append(backward)
+
+    # ---- gradient-writer bookkeeping (plan time): who finishes d(activation)? ---------------------------
+    @staticmethod
+    def _root(act):
+        return act.parent if act.parent is not None else act
+
+    def _consume(self, act):
+        """forward build: one more op whose backward will write (part of) act's gradient"""
+        if act is not None and act.grad is not None:
+            self._root(act).n_cons += 1
+
+    def _is_last_writer(self, act):
+        r = self._root(act)
+        return r.n_written + 1 == r.n_cons
+
+    def _written(self, act):
+        self._root(act).n_written += 1
+
+    def _bnred_plan(self, target, a):
+        """`a` (ConvArgs of a dense stride-1 data gradient writing ALL of target.grad) is about to be emitted.
+        If it is the LAST writer of that gradient and the tensor is the output of one or two CBLs, let its
+        epilogue emit their BatchNorm-backward reduction partials: the producers then skip their reduce pass
+        (include/y5m.h: y5m_conv_args.bn_part). Returns nothing; marks producer.bnred."""
+        if not self.bnred or not self._is_last_writer(target):
+            return
+        # only where the extra epilogue work (silu', two FMAs, a read of y per element) is free: the HBM-bound
+        # pointwise kernel. On the MFMA-bound tiled kernel it cost more than the reduce pass it replaces
+        # (measured: conv +3.0 ms vs BN backward -2.0 ms with every eligible layer fused).
+        if self.bnred != "all" and not self.L.y5m_conv_is_pointwise(ctypes.byref(a), self.dtype):
+            return
+        segs = sorted(target.children, key=lambda c: c.c0) if target.children else [target]
+        if len(segs) > 2 or segs[0].c0 != 0 or sum(c.C for c in segs) != target.C:
+            return
+        if len(segs) == 2 and segs[1].c0 != segs[0].C:
+            return
+        prods = [c.producer for c in segs]
+        if all(p is None for p in prods) or segs[0].C % 48 != 0:
+            return
+        rows = (target.M + 127) // 128
+        part = torch.zeros((rows, 2, a.Np), dtype=torch.float32, device=self.dev)
+        a.bn_part, a.bn_split = part.data_ptr(), segs[0].C
+        for i, (seg, p) in enumerate(zip(segs, prods)):
+            if p is None:
+                continue
+            if i == 0:
+                a.bn_y, a.bn_ldy, a.bn_scale, a.bn_shift = p.y_ptr, p.y_ld, p.bn[0].data_ptr(), p.bn[1].data_ptr()
+            else:
+                a.bn_y2, a.bn_ldy2, a.bn_scale2, a.bn_shift2 = p.y_ptr, p.y_ld, p.bn[0].data_ptr(), p.bn[1].data_ptr()
+            p.bnred = (part, part.data_ptr() + 4 * seg.c0, a.Np, rows)
+
+    def _bn_backward_op(self, lay, P, dz, scratch_ptr, lddy):
+        """the BatchNorm + SiLU backward launch list entry of one CBL: from the partials its gradient's last
+        writer left (lay.bnred) when there are any, else the standalone reduce + finalise + apply"""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        bn = lay.bn
+        red = getattr(lay, "bnred", None)
+        if red is not None:
+            _keep, pptr, ldp, rows = red
+            return (lambda: _lib.check(
+                L.y5m_bn_bwd_from_partials(pptr, rows, ldp, dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(),
+                                           bn[1].data_ptr(), bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU,
+                                           _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr, lddy, _lib.ptr(self.bnws),
+                                           self._bnws_bytes, dt, st()), "y5m_bn_bwd_from_partials"), ())
+        return (lambda: _lib.check(
+            L.y5m_bn_bwd(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
+                         bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr,
+                         lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ())
 
     def _flush_lazy(self, act):
         """ops that materialise a pending lazy gradient of `act` (grad = lazy source): a copy. Called by every
@@ -381,6 +467,8 @@ class Engine:
             lay.cin_real, lay.cout, lay.k, lay.s, lay.p = x.C, cout, 1, 1, 0
             lay.kk, lay.ss, lay.pp, lay.M, lay.Ho, lay.Wo = 1, 1, 0, M, x.H, x.W
             lay.z, lay.off = dest, off
+            lay.y_ptr, lay.y_ld = y2.data_ptr() + off * esz, N2
+            dest.producer = lay
             lay.bn = torch.zeros((4, cout), dtype=torch.float32, device=self.dev)
             rows = cout if off == 0 else Np2 - cout          # the second job also zero-fills the row padding
             self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, x.C, 1, 1, 0, 0, 1, 1, 0, 1, 1,
@@ -388,6 +476,7 @@ class Engine:
             halves.append((lay, P))
             self.layers.append(lay)
         halves[0][0].pair_buffers = (wf, y2)             # the launch descriptors hold raw pointers: keep the tensors alive
+        self._consume(x)
         a = self._conv_args(x, wf, y2.data_ptr(), x.H, x.W, 1, 1, 0, N2, N2, EPI_RAW_STATS, Kp)
         halves[0][0].fwd_args = a
         self._stat_users.append(a)
@@ -428,12 +517,7 @@ class Engine:
             ops.append((self._join_op(slot), ()))
             for lay, P in halves:
                 ops.extend(self._flush_lazy(lay.z))
-                dz, bn = lay.z.grad, lay.bn
-                ops.append((lambda lay=lay, P=P, dz=dz, bn=bn: _lib.check(
-                    L.y5m_bn_bwd(dz.ptr, dz.ld, y2.data_ptr() + lay.off * esz, N2, bn[0].data_ptr(), bn[1].data_ptr(),
-                                 bn[2].data_ptr(), bn[3].data_ptr(), M, cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]),
-                                 0, scratch.data_ptr() + lay.off * esz, N2, _lib.ptr(self.bnws), self._bnws_bytes, dt,
-                                 st()), "y5m_bn_bwd"), ()))
+                ops.append(self._bn_backward_op(lay, P, lay.z.grad, scratch.data_ptr() + lay.off * esz, N2))
             wa = WgradArgs()
             wa.zeros = _lib.zero_page(self.dev).data_ptr()
             wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * gw_off
@@ -465,6 +549,8 @@ class Engine:
                 g.Cin, g.K, g.Kp, g.N, g.M = N2, N2, wd.shape[1], K, M
                 g.Hout, g.Wout, g.ldout, g.osy, g.osx, g.ooy, g.oox = x.H, x.W, x.grad.ld, 1, 1, 0, 0
                 g.epi, g.act, g.accumulate, g.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
+                self._bnred_plan(x, g)
+                self._written(x)
                 ops.append((_kind(lambda g=g: _lib.check(L.y5m_conv(ctypes.byref(g), dt, st()), "y5m_conv(pair dgrad)"),
                                   "conv_igemm"), ()))
             return ops
@@ -484,9 +570,13 @@ class Engine:
                                             "y5m_sppf_pool"), ()))
         if self.training:
             poolws = torch.zeros((L.y5m_maxpool5_bwd_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
+            for _ in range(3):
+                self._consume(cat)            # the three pool backward passes accumulate into slices of d(cat)
 
             def backward():
                 ops = []
+                for _ in range(3):
+                    self._written(cat)
                 g = [s.grad for s in sl]
                 # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)   (cascade of model.py:108-110)
                 for lvl in (2, 1, 0):
@@ -504,8 +594,11 @@ class Engine:
         self.fwd.append((lambda: _lib.check(L.y5m_upsample2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, dst.ptr, dst.ld, dt, st()),
                                             "y5m_upsample2x"), ()))
         if self.training:
+            self._consume(x)
+
             def backward():
                 pre = self._flush_lazy(x)
+                self._written(x)
                 acc = 1 if x.gw else 0
                 x.gw = True
                 return pre + [(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
@@ -532,6 +625,7 @@ class Engine:
         lay.fwd_args = a
         self._run_conv(self.fwd, a)
         if self.training:
+            self._consume(x)
             ldp = _rup(N, 16)                      # 255 -> 256: 16-byte rows for the MFMA operand loads
             M = x.M
             lay.gout = torch.zeros_like(out)       # d(loss)/d(logits), filled by the loss / autograd
@@ -565,6 +659,7 @@ class Engine:
                                        _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(head)")
                 ops.append((self._side_op([f_wg, f_up], slot), ()))
                 self._grad_done.append((lay.name, P["gw"].data_ptr()))
+                self._written(x)
                 acc = 1 if x.gw else 0
                 x.gw = True
                 a = ConvArgs()
@@ -635,7 +730,7 @@ class Engine:
         for a in self._stat_users:
             a.stats = self.stats.data_ptr()
         if self.training:
-            self.scratch2 = [torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev) for _ in range(2)]
+            self.scratch2 = [torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev) for _ in range(self.nslots)]
             self.scratch = self.scratch2[0]
             self.bnws = torch.zeros((self._bnws_bytes,), dtype=torch.uint8, device=self.dev)
             self.gw = torch.zeros((self._gw_floats,), dtype=torch.float32, device=self.dev)
@@ -649,13 +744,13 @@ class Engine:
                 self.bwd.extend(mk())
                 for name, addr in self._grad_done[n0:]:
                     self.bwd_marks.append((len(self.bwd), name, addr))
-            self.bwd.append((self._join_op(0), ()))
-            self.bwd.append((self._join_op(1), ()))
+            for sl in range(self.nslots):
+                self.bwd.append((self._join_op(sl), ()))
 
     # ------------------------------------------------------------------ side-stream overlap (backward)
     def _next_slot(self):
         self._slot_seq = getattr(self, "_slot_seq", -1) + 1
-        return self._slot_seq & 1
+        return self._slot_seq % self.nslots
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
