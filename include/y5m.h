@@ -221,6 +221,10 @@ int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t tota
 /* packed f32 gradient [Cout][ldg] (mode 0 or 2 ordering) -> [Cout][Cin][KH][KW] */
 int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
                      void* stream);
+/* Input stage on the device (utils/training_utils.py:98 `images.float()/255` and :11-28 multi_scale):
+ * uint8 (B,3,Hs,Ws) -> f32 (B,3,H,W) = F.interpolate(img/255, (H,W), "bilinear", align_corners=False);
+ * Hs==H && Ws==W is the plain /255 conversion. */
+int y5m_preprocess_u8(const unsigned char* img, int B, int Hs, int Ws, float* out, int H, int W, void* stream);
 /* images (B,3,H,W) f32 NCHW (model.py:210 input) -> (B,H/2,W/2,16) NHWC, ch=(dy*2+dx)*3+c */
 int y5m_s2d_input(const float* img, int B, int H, int W, void* out, int dtype, void* stream);
 

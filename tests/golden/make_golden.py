@@ -325,8 +325,30 @@ def g7_large_step(model):
     save("g7_large_step", **out)
 
 
+def g8_input_stage():
+    """reference input stage (utils/training_utils.py:98-100): images.float()/255 then multi_scale with a pinned
+    `random` seed: the chosen sizes for several seeds, and sampled output values for two of them"""
+    import random
+    from utils import training_utils as RT
+    rng = np.random.default_rng(8)
+    img = torch.from_numpy(rng.integers(0, 256, (2, 3, 96, 160), dtype=np.uint8))
+    out = {"img": img.numpy()}
+    sizes = []
+    for seed in range(12):
+        random.seed(seed)
+        o = RT.multi_scale(img.float() / 255, target_shape=640, max_stride=32)
+        sizes.append([seed, o.shape[2], o.shape[3]])
+        if seed in (0, 5):
+            flat = o.reshape(-1).numpy()
+            step = max(1, flat.size // 8192)
+            out[f"seed{seed}/sample"] = flat[::step][:8192].copy()
+            out[f"seed{seed}/step"] = np.array(step)
+    out["sizes"] = np.array(sizes)
+    save("g8_input_stage", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -336,3 +358,4 @@ if __name__ == "__main__":
     if "g6" in which: g6_decode_nms(model)
     if "g5" in which: g5_model(model)
     if "g7" in which: g7_large_step(model)
+    if "g8" in which: g8_input_stage()

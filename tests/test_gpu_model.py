@@ -186,3 +186,27 @@ def test_large_batch_native_steps_bf16(golden, use_graph, bnred, monkeypatch):
     assert abs(losses[0] - float(g["loss"])) <= 2e-2 * float(g["loss"]), (losses[0], float(g["loss"]))
     assert losses[-1] < losses[0], losses
     assert bool(torch.isfinite(m.flat_params).all())
+
+
+def test_input_stage_u8_golden(golden):
+    """device input stage (y5m_preprocess_u8): uint8 batch -> /255 -> bilinear multi_scale, against the
+    reference's own `images.float()/255` + multi_scale output for pinned seeds, and against ATen on a sweep of
+    sizes (identity, down, up, non-square); fp32, 2e-6 absolute (values are in [0,1])"""
+    import random
+    import torch.nn.functional as F
+    from yolov5m_amd.utils.training_utils import preprocess_u8, multi_scale_size
+    g = golden("g8_input_stage")
+    img = torch.from_numpy(g["img"])
+    for seed in (0, 5):
+        random.seed(seed)
+        hw = multi_scale_size(img.shape[2], img.shape[3], 640, 32)
+        got = preprocess_u8(img.to(DEV), hw).reshape(-1).cpu().numpy()
+        ref = g[f"seed{seed}/sample"]
+        np.testing.assert_allclose(got[::int(g[f"seed{seed}/step"])][:8192], ref, rtol=0, atol=2e-6)
+    gen = torch.Generator().manual_seed(3)
+    for (B, Hs, Ws, H, W) in ((1, 64, 64, 64, 64), (2, 96, 160, 64, 96), (2, 50, 70, 128, 160), (3, 33, 47, 32, 96),
+                              (1, 640, 640, 320, 352)):
+        u8 = torch.randint(0, 256, (B, 3, Hs, Ws), generator=gen, dtype=torch.uint8)
+        ref = F.interpolate(u8.float() / 255, size=(H, W), mode="bilinear", align_corners=False)
+        got = preprocess_u8(u8.to(DEV), (H, W)).cpu()
+        assert float((got - ref).abs().max()) <= 2e-6, (B, Hs, Ws, H, W)

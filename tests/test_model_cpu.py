@@ -42,3 +42,15 @@ def test_forward_refuses_cpu_and_bad_shapes():
     if not torch.cuda.is_available():
         with pytest.raises(_lib.Y5MError):
             m(torch.zeros(1, 3, 64, 64))
+
+
+def test_multi_scale_size_matches_reference_rng(golden):
+    """host logic of the device input stage: the resize target chosen for a pinned `random` seed equals the size
+    the reference's multi_scale produced (tests/golden/g8_input_stage.npz)"""
+    import random
+    from yolov5m_amd.utils.training_utils import multi_scale_size
+    g = golden("g8_input_stage")
+    h, w = g["img"].shape[2:]
+    for seed, nh, nw in g["sizes"].tolist():
+        random.seed(seed)
+        assert multi_scale_size(h, w, 640, 32) == (nh, nw)

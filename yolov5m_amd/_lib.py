@@ -103,6 +103,7 @@ _SIGS = {
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y5m_pack_weights_batched": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),
     "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "y5m_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y5m_bn_finalize_workspace_bytes": (c_size_t, [c_int]),
     "y5m_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

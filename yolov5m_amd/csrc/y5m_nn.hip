@@ -198,6 +198,45 @@ extern "C" int y5m_s2d_input(const float* img, int B, int H, int W, void* out, i
 }
 
 // =================================================================================================
+// input stage on the device: uint8 (B,3,Hs,Ws) -> float /255 -> bilinear resize to (H,W)
+//   == F.interpolate(img.float()/255, size=(H,W), mode="bilinear", align_corners=False), the reference's
+//   `images.float()/255` + multi_scale (utils/training_utils.py:11-28, :98-100) -- on the GPU the host only
+//   ships the uint8 batch (4x fewer bytes over PCIe) and no fp32 image ever exists on the host.
+// One thread per output pixel (3 channels); writes are coalesced along x in each channel plane.
+// =================================================================================================
+__global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int B, int Hs, int Ws, float* __restrict__ out,
+                                     int H, int W, float sh, float sw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H * W) return;
+    const int x = (int)(i % W);
+    int64_t t = i / W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    // ATen area_pixel_compute_source_index(align_corners=false): max(scale*(dst+0.5)-0.5, 0)
+    const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned char* p = img + ((size_t)b * 3 + c) * Hs * Ws;
+        // the reference divides by 255 BEFORE interpolating: same order here (v/255 is not exact in fp32)
+        const float v00 = (float)p[(size_t)y0 * Ws + x0] / 255.0f, v01 = (float)p[(size_t)y0 * Ws + x1] / 255.0f;
+        const float v10 = (float)p[(size_t)y1 * Ws + x0] / 255.0f, v11 = (float)p[(size_t)y1 * Ws + x1] / 255.0f;
+        out[(((size_t)b * 3 + c) * H + y) * W + x] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+
+extern "C" int y5m_preprocess_u8(const unsigned char* img, int B, int Hs, int Ws, float* out, int H, int W, void* stream) {
+    Y5M_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0, "shape");
+    const int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), img, B, Hs, Ws, out, H, W,
+                       (float)Hs / (float)H, (float)Ws / (float)W);
+    Y5M_CHECK_LAUNCH("preprocess_u8_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
 // BatchNorm (training): finalise statistics from the conv epilogue partials
 // =================================================================================================
 // stats [tiles_m][2][Np] (sum, sumsq) -> mean, biased var; scale = g*invstd, shift = b - mean*scale;

@@ -30,6 +30,30 @@ def multi_scale(img, target_shape, max_stride):
     return nn.functional.interpolate(img, size=ns, mode="bilinear", align_corners=False)
 
 
+def multi_scale_size(h, w, target_shape, max_stride):
+    """the (new_h, new_w) multi_scale would resize an (h, w) batch to (same RNG draw as the reference)"""
+    sz = random.randrange(int(target_shape * 0.5), int(target_shape + max_stride)) // max_stride * max_stride
+    sf = sz / max(h, w)
+    return tuple(math.ceil(i * sf / max_stride) * max_stride for i in (h, w))
+
+
+def preprocess_u8(images_u8, out_hw=None, out=None):
+    """Device-side input stage: uint8 (B,3,Hs,Ws) on the GPU -> float32 (B,3,H,W) in [0,1], bilinear-resized
+    when out_hw differs from the source size: reference `images.float()/255` (:98) + multi_scale (:11-28) in
+    ONE native kernel (y5m_preprocess_u8); only the uint8 batch crosses PCIe."""
+    _lib.require_cuda(images_u8)
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[1] != 3:
+        raise _lib.Y5MError("preprocess_u8: expected a uint8 (B,3,H,W) tensor")
+    img = images_u8.contiguous()
+    B, _, Hs, Ws = img.shape
+    H, W = out_hw if out_hw is not None else (Hs, Ws)
+    if out is None:
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().y5m_preprocess_u8(_lib.ptr(img), B, Hs, Ws, _lib.ptr(out), H, W, _lib.stream_ptr()),
+               "y5m_preprocess_u8")
+    return out
+
+
 def train_loop(model, loader, optim, loss_fn, scaler=None, epoch=0, num_epochs=1, multi_scale_training=True):
     """reference utils/training_utils.py:81-132 (tqdm/printing dropped; returns the mean loss)."""
     nbs = 64                                                   # :87 nominal batch size
@@ -40,10 +64,15 @@ def train_loop(model, loader, optim, loss_fn, scaler=None, epoch=0, num_epochs=1
     nb = len(loader)
     optim.zero_grad()
     for idx, (images, bboxes) in enumerate(loader):
-        images = images.float() / 255                          # :98
-        if multi_scale_training:
-            images = multi_scale(images, target_shape=640, max_stride=32)
-        images = images.to(config.DEVICE, non_blocking=True)   # :102
+        if images.dtype == torch.uint8:
+            # same arithmetic as :98-102, on the device: ship the uint8 batch, /255 + bilinear resize natively
+            hw = multi_scale_size(images.shape[2], images.shape[3], 640, 32) if multi_scale_training else None
+            images = preprocess_u8(images.to(config.DEVICE, non_blocking=True), hw)
+        else:
+            images = images.float() / 255                      # :98
+            if multi_scale_training:
+                images = multi_scale(images, target_shape=640, max_stride=32)
+            images = images.to(config.DEVICE, non_blocking=True)   # :102
         out = model(images)                                    # :107
         loss = loss_fn(out, bboxes, pred_size=images.shape[2:4], batch_idx=idx, epoch=epoch)
         loss_epoch += float(loss.detach())
