@@ -210,3 +210,70 @@ def test_input_stage_u8_golden(golden):
         ref = F.interpolate(u8.float() / 255, size=(H, W), mode="bilinear", align_corners=False)
         got = preprocess_u8(u8.to(DEV), (H, W)).cpu()
         assert float((got - ref).abs().max()) <= 2e-6, (B, Hs, Ws, H, W)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_native_gradient_accumulation_matches_torch(use_graph):
+    """train_loop's accumulation (reference utils/training_utils.py:87-89, :116-121): two micro-batches summed,
+    then ONE clip + Adam -- NativeTrainStep(accumulate=2) against autograd + torch.optim.Adam on the same model"""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    xs = [synth_images(2, 96, 128, seed=f"acc{i}").to(DEV) for i in range(2)]
+    ts = [synth_labels(2, 5, seed=f"acclab{i}") for i in range(2)]
+    m1 = _model("f32"); m1.train()
+    opt = torch.optim.Adam(m1.parameters(), lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY)
+    lf1 = ComputeLoss(m1)
+    opt.zero_grad()
+    for x, t in zip(xs, ts):
+        lf1(m1(x), t, None).backward()
+    torch.nn.utils.clip_grad_norm_(m1.parameters(), max_norm=10.0)
+    opt.step()
+    m2 = _model("f32"); m2.train()
+    step = NativeTrainStep(m2, ComputeLoss(m2), nt_max=64, accumulate=2, use_graph=use_graph)
+    p_before = m2.flat_params.clone()
+    step.step(xs[0], ts[0])
+    assert torch.equal(m2.flat_params, p_before)              # no optimizer step after the first micro-batch
+    step.step(xs[1], ts[1])
+    p1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu().numpy()
+    p0 = p_before.cpu().numpy()
+    p2 = m2.flat_params.cpu().numpy()
+    d1, d2 = p1 - p0, p2 - p0
+    assert np.abs(d1).max() > 0
+    assert np.abs(d1 - d2).max() <= 2e-2 * np.abs(d1).max(), (np.abs(d1 - d2).max(), np.abs(d1).max())
+    # a second optimizer step through the same (replayed) graphs, and flush() on a partial accumulation
+    step.step(xs[0], ts[0]); step.flush()
+    assert bool(torch.isfinite(m2.flat_params).all()) and not torch.equal(m2.flat_params.cpu(), torch.from_numpy(p2))
+
+
+def test_native_optimizer_state_is_torch_adam_state():
+    """checkpoint interop (reference utils/utils.py:56-82): after two native steps the exported optimizer state
+    loads into torch.optim.Adam and the THIRD step taken by torch equals the third native step; and the
+    reverse direction (torch state -> native)"""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    x = synth_images(2, 96, 128).to(DEV)
+    t = synth_labels(2, 5, seed="lab3")
+    m2 = _model("f32"); m2.train()
+    nat = NativeTrainStep(m2, ComputeLoss(m2), nt_max=64)
+    nat.step(x, t); nat.step(x, t)
+    sd_model = {k: v.clone() for k, v in m2.state_dict().items()}
+    sd_opt = nat.optimizer_state_dict()
+    p_before = m2.flat_params.clone().cpu().numpy()
+    # torch takes step 3 from the exported state
+    m1 = _model("f32"); m1.load_state_dict(sd_model, strict=True); m1.train()
+    opt = torch.optim.Adam(m1.parameters(), lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY)
+    opt.load_state_dict(sd_opt)
+    ComputeLoss(m1)(m1(x), t, None).backward()
+    torch.nn.utils.clip_grad_norm_(m1.parameters(), max_norm=10.0)
+    opt.step()
+    nat.step(x, t)                                             # native step 3
+    d1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu().numpy() - p_before
+    d2 = m2.flat_params.cpu().numpy() - p_before
+    assert np.abs(d1 - d2).max() <= 2e-2 * np.abs(d1).max(), (np.abs(d1 - d2).max(), np.abs(d1).max())
+    # torch state (after its step 3) -> a fresh native stepper: same exp_avg / step counter
+    m3 = _model("f32"); m3.load_state_dict({k: v.clone() for k, v in m1.state_dict().items()}, strict=True); m3.train()
+    nat3 = NativeTrainStep(m3, ComputeLoss(m3), nt_max=64)
+    nat3.load_optimizer_state_dict(opt.state_dict())
+    assert int(nat3.d_step.item()) == 3
+    ref_m = torch.cat([opt.state_dict()["state"][i]["exp_avg"].reshape(-1) for i in range(len(list(m1.parameters())))])
+    np.testing.assert_allclose(nat3.m.cpu().numpy(), ref_m.cpu().numpy(), rtol=0, atol=0)

@@ -54,3 +54,35 @@ def test_multi_scale_size_matches_reference_rng(golden):
     for seed, nh, nw in g["sizes"].tolist():
         random.seed(seed)
         assert multi_scale_size(h, w, 640, 32) == (nh, nw)
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """reference utils/utils.py:56-82: {"state_dict", "optimizer"} in <folder>/<name>/checkpoint_epoch_<e>.pth.tar;
+    a checkpoint written with a torch.optim.Adam state (what the reference writes) loads back into the model and
+    into an optimizer through the mirrored helpers"""
+    import torch
+    from yolov5m_amd import config
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd.utils import utils as U
+    from yolov5m_amd.utils.synth import synth_state_dict
+    m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+    m.load_state_dict(synth_state_dict(), strict=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 0.01)
+    opt.step()
+    U.save_checkpoint(U.make_checkpoint(m, opt), str(tmp_path), "run", 3)
+    assert (tmp_path / "run" / "checkpoint_epoch_3.pth.tar").exists()
+    m2 = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+    saved_dev, config.DEVICE = config.DEVICE, "cpu"
+    try:
+        U.load_model_checkpoint("run", m2, 3, root=str(tmp_path))
+        opt2 = torch.optim.Adam(m2.parameters(), lr=5e-4)
+        U.load_optim_checkpoint("run", opt2, 3, root=str(tmp_path))
+    finally:
+        config.DEVICE = saved_dev
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert opt2.state_dict()["param_groups"][0]["lr"] == 1e-3
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert len(s1) == len(s2) and all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)

@@ -96,8 +96,14 @@ class NativeTrainStep:
     all-reduce plugs in here)."""
 
     def __init__(self, model, loss_fn, lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY, max_norm=10.0,
-                 betas=(0.9, 0.999), eps=1e-8, nt_max=1024, use_graph=False, grad_hook=None):
+                 betas=(0.9, 0.999), eps=1e-8, nt_max=1024, use_graph=False, grad_hook=None, accumulate=1):
+        """accumulate: micro-batches per optimizer step (reference train_loop :87-89, `nbs=64 / batch_size`):
+        gradients of `accumulate` consecutive step() calls are SUMMED (the loss is already scaled by the batch
+        size, ultralytics_loss.py:118) and clip + Adam run on the sum; flush() forces the step at an epoch end."""
         self.model, self.loss_fn = model, loss_fn
+        self.accumulate = max(int(accumulate), 1)
+        self._micro = 0
+        self.gacc = None
         self.lr, self.wd, self.max_norm, self.betas, self.eps = lr, weight_decay, max_norm, betas, eps
         self.nt_max = nt_max
         self.use_graph = use_graph
@@ -119,6 +125,8 @@ class NativeTrainStep:
         self._graph = None
         self._key = None
         self._ws = None
+        if self.accumulate > 1:
+            self.gacc = torch.zeros(n, dtype=torch.float32, device=dev)
 
     # forward + build-targets + loss (+ d loss / d logits) + backward: everything before the optimizer
     def _enqueue_fb(self, eng, timeline=None):
@@ -156,14 +164,18 @@ class NativeTrainStep:
         n = model.flat_params.numel()
         st = _lib.stream_ptr()
 
+        grads = self.gacc if self.gacc is not None else model.flat_grads
+
         def opt_ops():
             self.d_step.add_(1)
-            _lib.check(L.y5m_grad_norm(_lib.ptr(model.flat_grads), n, _lib.ptr(self.gnorm), _lib.ptr(self.aws),
+            _lib.check(L.y5m_grad_norm(_lib.ptr(grads), n, _lib.ptr(self.gnorm), _lib.ptr(self.aws),
                                        self.aws_bytes, st), "y5m_grad_norm")
-            _lib.check(L.y5m_adam_step(_lib.ptr(model.flat_params), _lib.ptr(model.flat_grads), _lib.ptr(self.m),
+            _lib.check(L.y5m_adam_step(_lib.ptr(model.flat_params), _lib.ptr(grads), _lib.ptr(self.m),
                                        _lib.ptr(self.v), n, _lib.ptr(self.gnorm), float(self.max_norm),
                                        float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                        float(self.wd), _lib.ptr(self.d_step), st), "y5m_adam_step")
+            if self.gacc is not None:
+                self.gacc.zero_()
         opt_ops.kind = "optimizer"
         from ..engine import Engine
         Engine._run([(opt_ops, ())], timeline)
@@ -186,6 +198,8 @@ class NativeTrainStep:
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
         key = (id(eng),)
+        if self.accumulate > 1:
+            return self._step_accumulate(eng, key)
         if not self.use_graph:
             self._enqueue_fb(eng)
             if self.grad_hook is not None:
@@ -221,6 +235,87 @@ class NativeTrainStep:
             self.grad_hook(self.model.flat_grads)
         g2.replay()
         return self.loss_out
+
+    def _step_accumulate(self, eng, key):
+        """micro-batch: forward/backward (+ graph replay) then gacc += grads; every `accumulate`-th call the
+        all-reduce hook, clip + Adam on the sum, and gacc = 0"""
+        if self.use_graph and (self._graph is None or self._key != key):
+            self._enqueue_fb(eng)                                  # eager warm-up == this call's micro-batch
+            self.gacc.add_(self.model.flat_grads)
+            torch.cuda.synchronize()
+            try:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    self._enqueue_fb(eng)
+                    self.gacc.add_(self.model.flat_grads)
+                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                    self._optimizer()
+                self._graph, self._key = (g1, g2), key
+            except Exception as e:
+                import warnings
+                warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
+                torch.cuda.synchronize()
+                self.use_graph = False
+                eng._pending.clear()
+        elif self.use_graph:
+            self._graph[0].replay()
+        else:
+            self._enqueue_fb(eng)
+            self.gacc.add_(self.model.flat_grads)
+        self._micro += 1
+        if self._micro >= self.accumulate:
+            self.flush()
+        return self.loss_out
+
+    def flush(self):
+        """optimizer step on whatever has been accumulated (reference: `idx == nb-1`, the epoch's last batch)"""
+        if self.accumulate <= 1 or self._micro == 0:
+            return
+        if self.grad_hook is not None:
+            self.grad_hook(self.gacc)
+        if self.use_graph and self._graph is not None:
+            self._graph[1].replay()
+        else:
+            self._optimizer()
+        self._micro = 0
+
+    # ---- optimizer state <-> torch.optim.Adam (the reference's checkpoint format, utils/utils.py:56-82) ----
+    def optimizer_state_dict(self):
+        """{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} exactly as
+        torch.optim.Adam(model.parameters(), lr, weight_decay).state_dict() would hold it: parameter i is the
+        i-th entry of model.parameters(); the flat m / v buffers are split back into per-parameter tensors."""
+        params = list(self.model.parameters())
+        step = int(self.d_step.item())
+        state, off = {}, 0
+        for i, p in enumerate(params):
+            k = p.numel()
+            if step > 0:
+                state[i] = {"step": torch.tensor(float(step)),
+                            "exp_avg": self.m[off:off + k].view_as(p).clone(),
+                            "exp_avg_sq": self.v[off:off + k].view_as(p).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """inverse of optimizer_state_dict(); accepts a torch.optim.Adam state_dict of the same model"""
+        params = list(self.model.parameters())
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        off, step = 0, 0
+        self.m.zero_(); self.v.zero_()
+        for i, p in enumerate(params):
+            k = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                step = max(step, int(float(st["step"])))
+            off += k
+        self.d_step.fill_(step)
+        self._graph = None                         # captured scalars (lr, betas) may have changed
 
     def profile_step(self, images, targets):
         """One EAGER step with a HIP event pair around every launch (recorded on the launch stream).
