@@ -296,11 +296,18 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         if (minch < 0) { const char* e = getenv("Y5M_WGRAD_MINCH"); minch = e ? atoi(e) : 8; }
         const int base = P.tiles_n * P.tiles_c * taps;
         // measured (MI355X, B=64): every split adds one f32 atomic per output element, so pointwise layers
-        // (few, large output tiles) want ~1 block per CU, 3x3 layers ~4 per CU, the 48x16 stem tile more
-        // multi-tap tiles are LDS-heavy (1-2 blocks per CU): one resident round
+        // (few, large output tiles) want ~1 block per CU. 3x3 layers: fill the chip with ONE resident round --
+        // blocks <= resident capacity (a second, nearly empty round cost 20 %: 137 -> 111 us on the 192x192
+        // layers when the count dropped from 522 to <= 512); capacity = blocks per CU (LDS / VGPR limited:
+        // 2 for the 96x48 wave tile, 3 otherwise) x 256 CUs. The 48x16 stem tile (one tap per block) wants more.
         const int per_cu = (int)((160 * 1024) / (2 * (size_t)(C::YB + C::XB)));
-        const int tgt = target > 0 ? target : (TPB > 1 ? 256 * (per_cu < 1 ? 1 : per_cu) : (taps == 1 ? 320 : (C::TC <= 16 ? 2048 : 1024)));
-        int ks = (tgt + base - 1) / base;
+        const int resident = 256 * (NFR == 6 ? 2 : (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu)));
+        int ks;
+        if (target > 0) ks = (target + base - 1) / base;
+        else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
+        else if (taps == 1) ks = (320 + base - 1) / base;
+        else if (C::TC <= 16) ks = (2048 + base - 1) / base;
+        else ks = resident / base;                          // floor: never more blocks than fit at once
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
         P.ksplit = ks < 1 ? 1 : ks;
