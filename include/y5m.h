@@ -70,6 +70,14 @@ size_t y5m_nms_workspace_bytes(int B, int64_t N);
 int y5m_nms(const float* boxes, int B, int64_t N, float conf_threshold, double iou_threshold,
             int max_det, float* out_rows, int32_t* out_idx, int32_t* out_count, void* ws,
             size_t ws_bytes, void* stream);
+/* non_max_suppression_aladdin (utils/bboxes_utils.py:129-173) for B independent lists of N rows
+ * [class, score, c0, c1, c2, c3] (corners x1,y1,x2,y2 or, midpoint != 0, x,y,w,h): rows with score > threshold
+ * (double compare), stable descending score order, TRUNCATED to max_det, then a kept row removes later rows of
+ * the same class whose A8 IoU (fp32, eps 1e-7) is >= float32(iou_threshold). out_rows: the kept rows unchanged,
+ * out_idx: their indices in the input list. Workspace as y5m_nms. */
+int y5m_nms_aladdin(const float* boxes, int B, int64_t N, double threshold, float iou_threshold, int midpoint,
+                    int max_det, float* out_rows, int32_t* out_idx, int32_t* out_count, void* ws, size_t ws_bytes,
+                    void* stream);
 
 /* Replaces utils/bboxes_utils.py:33-87 intersection_over_union(box_format="midpoint").
  * a,b (n,4) f32 -> out (n) ; giou != 0 selects GIoU. */

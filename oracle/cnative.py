@@ -27,6 +27,8 @@ def lib():
         L.orc_nms_tv012.argtypes = [p, p, i64, ctypes.c_double, p]
         L.orc_non_max_suppression.restype = i64
         L.orc_non_max_suppression.argtypes = [p, i64, ctypes.c_float, ctypes.c_double, i64, p, p]
+        L.orc_nms_aladdin.restype = i64
+        L.orc_nms_aladdin.argtypes = [p, i64, ctypes.c_double, ctypes.c_float, ctypes.c_int, i64, p]
         L.orc_build_targets_ultra.restype = i64
         L.orc_build_targets_ultra.argtypes = [p, i64, p, i64, i64, i64, ctypes.c_float,
                                               p, p, p, p, p, p, p]
@@ -56,6 +58,15 @@ def non_max_suppression_image(boxes, iou_threshold, threshold, max_detections=30
     k = lib().orc_non_max_suppression(_ptr(boxes), N, float(threshold), float(iou_threshold),
                                       int(max_detections), _ptr(out), _ptr(idx))
     return out[:k].copy(), idx[:k].copy()
+
+
+def nms_aladdin(boxes, iou_threshold, threshold, box_format="corners", max_detections=300):
+    """reference utils/bboxes_utils.py:129-173 for one list: (N,6) rows -> kept indices (keep order)"""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    idx = np.empty(max(boxes.shape[0], 1), dtype=np.int64)
+    k = lib().orc_nms_aladdin(_ptr(boxes), boxes.shape[0], float(threshold), float(iou_threshold),
+                              1 if box_format == "midpoint" else 0, int(max_detections), _ptr(idx))
+    return idx[:k].copy()
 
 
 def build_targets_ultra_scale(targets, anchors, ny, nx, anchor_t=4.0):

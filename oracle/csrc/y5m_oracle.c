@@ -127,6 +127,60 @@ int64_t orc_non_max_suppression(const float *boxes, int64_t N, float threshold, 
     return k;
 }
 
+/* reference utils/bboxes_utils.py:129-173 non_max_suppression_aladdin for ONE list.
+ * in : boxes (N,6) rows [class, score, c0, c1, c2, c3] (fp32: torch.tensor(list) rounds the Python floats);
+ *      midpoint != 0 <=> box_format == "midpoint"
+ * out: out_idx = indices (into the input list) of the kept rows, in keep order. returns #kept.
+ * :149 filter `score > threshold` on Python floats (double compare); :150 stable sort, descending score;
+ * :151-152 truncate to max_det BEFORE suppression; :154-171 a chosen box removes the later boxes of the same
+ * class unless intersection_over_union(chosen, box) < iou_threshold (A8, :33-87, fp32 tensors: the Python
+ * threshold is compared in float32). */
+static float orc_iou_a8(const float *a, const float *b, int midpoint) {
+    float b1x1, b1y1, b1x2, b1y2, b2x1, b2y1, b2x2, b2y2;
+    if (midpoint) {                                   /* :52-60 */
+        b1x1 = a[0] - a[2] / 2.0f; b1y1 = a[1] - a[3] / 2.0f; b1x2 = a[0] + a[2] / 2.0f; b1y2 = a[1] + a[3] / 2.0f;
+        b2x1 = b[0] - b[2] / 2.0f; b2y1 = b[1] - b[3] / 2.0f; b2x2 = b[0] + b[2] / 2.0f; b2y2 = b[1] + b[3] / 2.0f;
+    } else {                                          /* :62-70 */
+        b1x1 = a[0]; b1y1 = a[1]; b1x2 = a[2]; b1y2 = a[3];
+        b2x1 = b[0]; b2y1 = b[1]; b2x2 = b[2]; b2y2 = b[3];
+    }
+    const float w1 = b1x2 - b1x1, h1 = b1y2 - b1y1, w2 = b2x2 - b2x1, h2 = b2y2 - b2y1;      /* :72 */
+    float iw = (b1x2 < b2x2 ? b1x2 : b2x2) - (b1x1 > b2x1 ? b1x1 : b2x1);                      /* :74 */
+    float ih = (b1y2 < b2y2 ? b1y2 : b2y2) - (b1y1 > b2y1 ? b1y1 : b2y1);                      /* :75 */
+    iw = iw > 0.0f ? iw : 0.0f; ih = ih > 0.0f ? ih : 0.0f;
+    const float inter = iw * ih;
+    const float uni = w1 * h1 + w2 * h2 - inter + 1e-7f;                                        /* :78 */
+    return inter / uni;                                                                         /* :80 */
+}
+
+int64_t orc_nms_aladdin(const float *boxes, int64_t N, double threshold, float iou_threshold, int midpoint,
+                        int64_t max_det, int64_t *out_idx) {
+    int64_t *idx = (int64_t *)malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
+    int64_t *tmp = (int64_t *)malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
+    float *sc = (float *)malloc((size_t)(N > 0 ? N : 1) * sizeof(float));
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; ++i)
+        if ((double)boxes[6 * i + 1] > threshold) idx[n++] = i;                                 /* :149 */
+    for (int64_t i = 0; i < N; ++i) sc[i] = boxes[6 * i + 1];
+    merge_sort_desc(sc, idx, tmp, n);                 /* :150 stable: equal scores keep the list order */
+    if (n > max_det) n = max_det;                     /* :151-152 */
+    char *dead = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        const float *ci = boxes + 6 * idx[i];
+        out_idx[k++] = idx[i];
+        for (int64_t j = i + 1; j < n; ++j) {
+            if (dead[j]) continue;
+            const float *cj = boxes + 6 * idx[j];
+            if (cj[0] != ci[0]) continue;                                                       /* :163 */
+            if (!(orc_iou_a8(ci + 2, cj + 2, midpoint) < iou_threshold)) dead[j] = 1;           /* :164-168 */
+        }
+    }
+    free(idx); free(tmp); free(sc); free(dead);
+    return k;
+}
+
 /* python-style remainder a % 1.0 (torch.remainder) */
 static float py_mod1(float a) {
     float r = fmodf(a, 1.0f);

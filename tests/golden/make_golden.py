@@ -303,6 +303,40 @@ def g6_decode_nms(model):
     save("g6_decode_nms", **out)
 
 
+def g9_nms_aladdin():
+    """reference non_max_suppression_aladdin (utils/bboxes_utils.py:129-173) on seeded lists: kept indices"""
+    from utils import bboxes_utils as RB
+    rng = np.random.default_rng(9)
+    out, names = {}, []
+    def run(name, bx, thr, iou, fmt, md):
+        lst = [[float(v) for v in row] for row in bx]
+        # kept rows are identified by object identity (the reference returns the list objects it was given)
+        plain = [r[:6] for r in lst]
+        kept = RB.non_max_suppression_aladdin(plain, iou, thr, box_format=fmt, max_detections=md)
+        pos = {id(r): i for i, r in enumerate(plain)}
+        out[f"{name}/in"] = bx
+        out[f"{name}/par"] = np.array([thr, iou, 1.0 if fmt == "midpoint" else 0.0, md])
+        out[f"{name}/keep"] = np.array([pos[id(r)] for r in kept], dtype=np.int64)
+        names.append(name)
+    for N in (0, 1, 50, 400, 1500):
+        for fmt in ("corners", "midpoint"):
+            bx = np.zeros((N, 6), np.float32)
+            bx[:, 0] = rng.integers(0, 4, N)
+            bx[:, 1] = (rng.uniform(0, 1, N) ** 2).astype(np.float32)
+            if N >= 50:
+                bx[::7, 1] = bx[3, 1]                  # score ties: the stable order decides
+            c = rng.uniform(50, 400, (N, 2)).astype(np.float32)
+            wh = rng.uniform(20, 120, (N, 2)).astype(np.float32)
+            if fmt == "corners":
+                bx[:, 2:4], bx[:, 4:6] = c - wh / 2, c + wh / 2
+            else:
+                bx[:, 2:4], bx[:, 4:6] = c, wh
+            run(f"n{N}_{fmt}_a", bx, 0.05, 0.5, fmt, 300)
+            run(f"n{N}_{fmt}_b", bx, 0.3, 0.3, fmt, 40)
+    out["names"] = np.array(names)
+    save("g9_nms_aladdin", **out)
+
+
 def g7_large_step(model):
     """first train-mode forward + ComputeLoss of the reference at a batch large enough that every layer width
     runs its multi-workgroup reductions (B=16 @ 320x320): the loss and its 3 components, and sampled logits"""
@@ -348,7 +382,7 @@ def g8_input_stage():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -359,3 +393,4 @@ if __name__ == "__main__":
     if "g5" in which: g5_model(model)
     if "g7" in which: g7_large_step(model)
     if "g8" in which: g8_input_stage()
+    if "g9" in which: g9_nms_aladdin()

@@ -292,3 +292,31 @@ def test_yolo_loss_single_scale_and_nan(anchors):
     # no boxes at all -> NaN, as the reference (loss.py:212)
     l = lf([t.to(DEV) for t in p], (np.zeros((0, 5)), np.zeros((0, 5))), pred_size=(64, 64))
     assert bool(torch.isnan(l))
+
+
+def test_nms_aladdin_golden_and_oracle(golden):
+    """non_max_suppression_aladdin through the C ABI (y5m_nms_aladdin): the kept boxes are the SAME list objects
+    in the same order as the real reference kept (golden), and as the C oracle keeps on larger lists (bit-exact
+    index sets: integer / compare work)"""
+    import numpy as np
+    from oracle import cnative
+    from yolov5m_amd.utils.bboxes_utils import non_max_suppression_aladdin
+    g = golden("g9_nms_aladdin")
+    for name in g["names"].tolist():
+        thr, iou, mid, md = g[f"{name}/par"].tolist()
+        lst = [[float(v) for v in row] for row in g[f"{name}/in"]]
+        kept = non_max_suppression_aladdin(lst, iou, thr, box_format="midpoint" if mid else "corners", max_detections=int(md))
+        pos = {id(r): i for i, r in enumerate(lst)}
+        assert [pos[id(r)] for r in kept] == g[f"{name}/keep"].tolist(), name
+    rng = np.random.default_rng(5)
+    for N, md, fmt in ((25200, 300, "corners"), (6000, 1000, "midpoint"), (5000, 17, "corners")):
+        bx = np.zeros((N, 6), np.float32)
+        bx[:, 0] = rng.integers(0, 80, N)
+        bx[:, 1] = rng.uniform(0, 1, N).astype(np.float32)
+        c, wh = rng.uniform(0, 640, (N, 2)).astype(np.float32), rng.uniform(4, 200, (N, 2)).astype(np.float32)
+        bx[:, 2:4], bx[:, 4:6] = (c, wh) if fmt == "midpoint" else (c - wh / 2, c + wh / 2)
+        lst = bx.tolist()
+        kept = non_max_suppression_aladdin(lst, 0.45, 0.25, box_format=fmt, max_detections=md)
+        pos = {id(r): i for i, r in enumerate(lst)}
+        assert [pos[id(r)] for r in kept] == cnative.nms_aladdin(bx, 0.45, 0.25, fmt, md).tolist(), (N, md, fmt)
+    assert non_max_suppression_aladdin([], 0.5, 0.5) == []

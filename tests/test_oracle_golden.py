@@ -163,3 +163,14 @@ def test_nms_vs_reference_pure_python_aladdin():
         ovr = inter / (area[i] + area - inter)
         alive &= ~(ovr.astype(np.float64) > 0.5)
     assert list(keep) == ref
+
+
+def test_oracle_nms_aladdin_matches_reference(golden):
+    """non_max_suppression_aladdin (reference utils/bboxes_utils.py:129-173): the C restatement against the kept
+    lists the real reference produced (corners / midpoint, score ties, truncation before suppression)"""
+    from oracle import cnative
+    g = golden("g9_nms_aladdin")
+    for name in g["names"].tolist():
+        thr, iou, mid, md = g[f"{name}/par"].tolist()
+        keep = cnative.nms_aladdin(g[f"{name}/in"], iou, thr, "midpoint" if mid else "corners", int(md))
+        assert keep.tolist() == g[f"{name}/keep"].tolist(), name

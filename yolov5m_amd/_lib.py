@@ -80,6 +80,8 @@ _SIGS = {
     "y5m_decode_targets_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64,
                                          c_int64, c_void_p]),
     "y5m_nms_workspace_bytes": (c_size_t, [c_int, c_int64]),
+    "y5m_nms_aladdin": (c_int, [c_void_p, c_int, c_int64, c_double, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
     "y5m_nms": (c_int, [c_void_p, c_int, c_int64, c_float, c_double, c_int, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_size_t, c_void_p]),
     "y5m_iou": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),

@@ -264,20 +264,39 @@ struct NmsLds {
 
 struct NmsBox { float x1, y1, x2, y2, area; };
 
+// MODE 0: reference non_max_suppression (utils/bboxes_utils.py:175-209 + torchvision nms)
+// MODE 1 / 2: non_max_suppression_aladdin (utils/bboxes_utils.py:129-173), box_format corners / midpoint:
+//   candidates truncated to max_detections BEFORE suppression; a kept box removes later boxes of the SAME class
+//   with intersection_over_union(kept, box) >= iou_threshold (A8: fp32, eps = 1e-7 in the union); rows are
+//   returned unchanged. NmsBox.area carries the class id in these modes.
 // reference utils/bboxes_utils.py:190-195 for one candidate row (exact op order)
+template <int MODE>
 __device__ __forceinline__ void nms_load(const float* __restrict__ row, float& cls, float& score,
                                          float& x1, float& y1, float& x2, float& y2, NmsBox& ob) {
     cls = row[0]; score = row[1];
-    const float x = row[2], y = row[3], w = row[4], h = row[5];
-    x1 = x - (w / 2.0f);          // :190
-    y1 = y - (h / 2.0f);          // :191
-    y2 = h + y1;                  // :192
-    x2 = w + x1;                  // :193
-    ob.x1 = x1 + cls; ob.y1 = y1 + cls; ob.x2 = x2 + cls; ob.y2 = y2 + cls;   // :195
-    ob.area = (ob.x2 - ob.x1) * (ob.y2 - ob.y1);
+    if constexpr (MODE == 0) {
+        const float x = row[2], y = row[3], w = row[4], h = row[5];
+        x1 = x - (w / 2.0f);          // :190
+        y1 = y - (h / 2.0f);          // :191
+        y2 = h + y1;                  // :192
+        x2 = w + x1;                  // :193
+        ob.x1 = x1 + cls; ob.y1 = y1 + cls; ob.x2 = x2 + cls; ob.y2 = y2 + cls;   // :195
+        ob.area = (ob.x2 - ob.x1) * (ob.y2 - ob.y1);
+    } else {
+        x1 = row[2]; y1 = row[3]; x2 = row[4]; y2 = row[5];                       // returned as given
+        if constexpr (MODE == 2) {    // bboxes_utils.py:52-60 (midpoint -> corners, the operation order of A8)
+            ob.x1 = row[2] - row[4] / 2.0f; ob.y1 = row[3] - row[5] / 2.0f;
+            ob.x2 = row[2] + row[4] / 2.0f; ob.y2 = row[3] + row[5] / 2.0f;
+        } else {
+            ob.x1 = x1; ob.y1 = y1; ob.x2 = x2; ob.y2 = y2;
+        }
+        ob.area = cls;
+    }
 }
 
-// torchvision nms_kernel.cpp inner test; i = already kept (higher score), j = candidate
+// MODE 0: torchvision nms_kernel.cpp inner test; i = already kept (higher score), j = candidate
+// MODE 1/2: bboxes_utils.py:160-168: drop j unless class differs or iou(i, j) < float32(threshold)
+template <int MODE>
 __device__ __forceinline__ bool nms_suppresses(float ix1, float iy1, float ix2, float iy2, float iarea,
                                                const NmsBox& j, double thr) {
     const float xx1 = ix1 > j.x1 ? ix1 : j.x1;
@@ -287,8 +306,16 @@ __device__ __forceinline__ bool nms_suppresses(float ix1, float iy1, float ix2, 
     float w = xx2 - xx1; w = w > 0.0f ? w : 0.0f;
     float h = yy2 - yy1; h = h > 0.0f ? h : 0.0f;
     const float inter = w * h;
-    const float ovr = inter / (iarea + j.area - inter);
-    return (double)ovr > thr;
+    if constexpr (MODE == 0) {
+        const float ovr = inter / (iarea + j.area - inter);
+        return (double)ovr > thr;
+    } else {
+        if (iarea != j.area) return false;                               // different class: kept (:163)
+        const float w1 = ix2 - ix1, h1 = iy2 - iy1, w2 = j.x2 - j.x1, h2 = j.y2 - j.y1;
+        const float uni = w1 * h1 + w2 * h2 - inter + 1e-7f;             // :78
+        const float iou = inter / uni;
+        return !(iou < (float)thr);                                      // kept only if iou < threshold (:164-168)
+    }
 }
 
 // order-preserving transform: larger score -> smaller key (ascending sort = best first)
@@ -309,8 +336,9 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
     return t;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(NMS_T) void nms_kernel(
-    const float* __restrict__ boxes, int64_t N, float conf_thr, double iou_thr, int max_det, int ibits,
+    const float* __restrict__ boxes, int64_t N, float conf_thr, double conf_thr_d, double iou_thr, int max_det, int ibits,
     float* __restrict__ out_rows, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_count,
     unsigned* __restrict__ ws_keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_raw[];
@@ -328,7 +356,8 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
     int my = 0;
     for (int64_t i = tid; i < N; i += NMS_T) {
         const float s = bx[i * 6 + 1];
-        const bool c = s > conf_thr;
+        // MODE 0: tensor > python float compares in float32 (:186); aladdin: python floats, i.e. doubles (:149)
+        const bool c = MODE == 0 ? s > conf_thr : (double)s > conf_thr_d;
         skey[i] = c ? desc_key(s) : 0xFFFFFFFFu;
         my += c ? 1 : 0;
     }
@@ -411,7 +440,7 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
             }
         }
         __syncthreads();
-        const int m = L.s_m < NMS_CAP ? L.s_m : NMS_CAP;
+        int m = L.s_m < NMS_CAP ? L.s_m : NMS_CAP;
         int n2 = 64;
         while (n2 < m) n2 <<= 1;
         for (int i = m + tid; i < n2; i += NMS_T) L.keys[i] = ~0ull;
@@ -428,6 +457,8 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
                 __syncthreads();
             }
         }
+        // aladdin (:151-152): only the max_detections best candidates enter the suppression at all
+        if (MODE != 0 && m > max_det) m = max_det;
         // ---- greedy scan of the sorted chunk ---------------------------------------------------
         for (int base = 0; base < m; base += NMS_T) {
             const int nk0 = L.s_nk;
@@ -438,11 +469,11 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
             if (valid) {
                 src = (int)(L.keys[ci] & imask);
                 float cls, sc, x1, y1, x2, y2;
-                nms_load(bx + (int64_t)src * 6, cls, sc, x1, y1, x2, y2, cb);
+                nms_load<MODE>(bx + (int64_t)src * 6, cls, sc, x1, y1, x2, y2, cb);
             }
             bool alive = valid;
             for (int k = 0; k < nk0 && alive; ++k) {
-                if (nms_suppresses(L.kbox[4 * k], L.kbox[4 * k + 1], L.kbox[4 * k + 2], L.kbox[4 * k + 3],
+                if (nms_suppresses<MODE>(L.kbox[4 * k], L.kbox[4 * k + 1], L.kbox[4 * k + 2], L.kbox[4 * k + 3],
                                    L.karea[k], cb, iou_thr))
                     alive = false;
             }
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
                     }
                     // boxes kept earlier in THIS group (after the block-wide test above)
                     for (int k = nk0; k < nk && al; ++k) {
-                        if (nms_suppresses(kbox[4 * k], kbox[4 * k + 1], kbox[4 * k + 2], kbox[4 * k + 3],
+                        if (nms_suppresses<MODE>(kbox[4 * k], kbox[4 * k + 1], kbox[4 * k + 2], kbox[4 * k + 3],
                                            karea[k], mb, iou_thr))
                             al = false;
                     }
@@ -497,14 +528,14 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
                             karea[nk] = ia;
                             float cls, sc, x1, y1, x2, y2;
                             NmsBox tmp;
-                            nms_load(bx + (int64_t)msrc * 6, cls, sc, x1, y1, x2, y2, tmp);
+                            nms_load<MODE>(bx + (int64_t)msrc * 6, cls, sc, x1, y1, x2, y2, tmp);
                             float* o = orow + (int64_t)nk * 6;
                             o[0] = cls; o[1] = sc; o[2] = x1; o[3] = y1; o[4] = x2; o[5] = y2;
                             oidx[nk] = msrc;
                             al = false;
                         }
                         ++nk;
-                        if (al && lane > i && nms_suppresses(ix1, iy1, ix2, iy2, ia, mb, iou_thr)) al = false;
+                        if (al && lane > i && nms_suppresses<MODE>(ix1, iy1, ix2, iy2, ia, mb, iou_thr)) al = false;
                         mask = __ballot(al);
                     }
                 }
@@ -518,6 +549,7 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
         lo_excl = T;
         remaining -= m;
         __syncthreads();
+        if (MODE != 0) break;            // aladdin: one pass over the truncated list
     }
     if (tid == 0) out_count[img] = L.s_nk;
 }
@@ -538,13 +570,43 @@ extern "C" int y5m_nms(const float* boxes, int B, int64_t N, float conf_threshol
     while ((1ll << ibits) < N) ++ibits;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsLds));
+        hipFuncSetAttribute((const void*)nms_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsLds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)B), dim3(NMS_T), sizeof(NmsLds), y5m_stream(stream),
-                       boxes, N, conf_threshold, iou_threshold, max_det, ibits, out_rows, out_idx, out_count,
-                       reinterpret_cast<unsigned*>(ws));
+    hipLaunchKernelGGL(nms_kernel<0>, dim3((unsigned)B), dim3(NMS_T), sizeof(NmsLds), y5m_stream(stream),
+                       boxes, N, conf_threshold, (double)conf_threshold, iou_threshold, max_det, ibits, out_rows, out_idx,
+                       out_count, reinterpret_cast<unsigned*>(ws));
     Y5M_CHECK_LAUNCH("nms_kernel");
+    return Y5M_OK;
+}
+
+// non_max_suppression_aladdin (reference utils/bboxes_utils.py:129-173) for B independent box lists of N rows
+// [class, score, 4 coordinates]; midpoint = box_format == "midpoint". Same workspace as y5m_nms.
+extern "C" int y5m_nms_aladdin(const float* boxes, int B, int64_t N, double threshold, float iou_threshold, int midpoint,
+                               int max_det, float* out_rows, int32_t* out_idx, int32_t* out_count, void* ws,
+                               size_t ws_bytes, void* stream) {
+    Y5M_REQUIRE(B >= 0 && N >= 0, "bad dims");
+    Y5M_REQUIRE(max_det >= 1 && max_det <= NMS_MAXK, "max_det must be in [1,1024]");
+    Y5M_REQUIRE(N < (1ll << 31), "N too large");
+    if (B == 0) return Y5M_OK;
+    if (ws_bytes < y5m_nms_workspace_bytes(B, N)) { y5m_set_error("nms workspace too small"); return Y5M_EWS; }
+    int ibits = 1;
+    while ((1ll << ibits) < N) ++ibits;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)nms_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsLds));
+        hipFuncSetAttribute((const void*)nms_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsLds));
+        attr_set = true;
+    }
+    if (midpoint)
+        hipLaunchKernelGGL(nms_kernel<2>, dim3((unsigned)B), dim3(NMS_T), sizeof(NmsLds), y5m_stream(stream), boxes, N,
+                           0.0f, threshold, (double)iou_threshold, max_det, ibits, out_rows, out_idx, out_count,
+                           reinterpret_cast<unsigned*>(ws));
+    else
+        hipLaunchKernelGGL(nms_kernel<1>, dim3((unsigned)B), dim3(NMS_T), sizeof(NmsLds), y5m_stream(stream), boxes, N,
+                           0.0f, threshold, (double)iou_threshold, max_det, ibits, out_rows, out_idx, out_count,
+                           reinterpret_cast<unsigned*>(ws));
+    Y5M_CHECK_LAUNCH("nms_kernel(aladdin)");
     return Y5M_OK;
 }
 

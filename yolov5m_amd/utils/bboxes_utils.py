@@ -88,6 +88,31 @@ def nms_batched(batch_bboxes, iou_threshold, threshold, max_detections=300):
     return rows, idx, cnt
 
 
+def non_max_suppression_aladdin(bboxes, iou_threshold, threshold, box_format="corners", max_detections=300):
+    """reference utils/bboxes_utils.py:129-173 (its own slow pure-Python baseline), same signature: a list of
+    [class_pred, prob_score, x1, y1, x2, y2] (or x, y, w, h with box_format="midpoint") -> the kept boxes (the
+    SAME list objects, keep order). Filter `score > threshold`, stable descending sort, truncation to
+    max_detections BEFORE suppression, same-class suppression at IoU >= iou_threshold -- one native launch
+    (y5m_nms_aladdin). Scores / coordinates are compared as float32 (the reference builds float32 tensors for the
+    IoU; its score filter and sort run on the Python floats, identical whenever those came from a float32 tensor)."""
+    assert type(bboxes) == list
+    if not bboxes:
+        return []
+    L = _lib.lib()
+    t = torch.tensor(bboxes, dtype=torch.float32, device="cuda").reshape(1, -1, 6).contiguous()
+    N = t.shape[1]
+    rows = torch.empty((1, max_detections, 6), dtype=torch.float32, device=t.device)
+    idx = torch.empty((1, max_detections), dtype=torch.int32, device=t.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=t.device)
+    wsb = L.y5m_nms_workspace_bytes(1, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=t.device)
+    _lib.check(L.y5m_nms_aladdin(_lib.ptr(t), 1, N, float(threshold), float(iou_threshold),
+                                 1 if box_format == "midpoint" else 0, int(max_detections), _lib.ptr(rows), _lib.ptr(idx),
+                                 _lib.ptr(cnt), _lib.ptr(ws), wsb, _lib.stream_ptr()), "y5m_nms_aladdin")
+    k = int(cnt.item())
+    return [bboxes[i] for i in idx[0, :k].tolist()]
+
+
 def non_max_suppression(batch_bboxes, iou_threshold, threshold, max_detections=300, tolist=True):
     """reference utils/bboxes_utils.py:175-209. batch_bboxes (B,N,6) rows [class, score, x, y, w, h].
     tolist=True -> list (per image) of lists of [class, score, x1, y1, x2, y2];
