@@ -337,6 +337,43 @@ def g9_nms_aladdin():
     save("g9_nms_aladdin", **out)
 
 
+def g10_config0(model):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case, ultralytics_files/my_loss_vs_ultra_loss.py
+    :26-33): torch.manual_seed(355); images = rand(4,3,640,640); 12 labels [img, cls, x, y, w, h] with
+    bboxes = randint(0,50,(12,4))/100. Weights: the counter-based generator (the script's are unseeded).
+    Stored: inputs' labels, train-mode logits samples, ComputeLoss, decode+NMS counts at (0.01, 0.6, 300)."""
+    sd = synth_state_dict()
+    torch.manual_seed(355)
+    images = torch.rand((4, 3, 640, 640))
+    img_idx = torch.arange(4).repeat(3, 1).T.reshape(12, 1)
+    classes = torch.arange(4).repeat(3, 1).T.reshape(12, 1)
+    bboxes = torch.randint(low=0, high=50, size=(12, 4)) / 100
+    labels = torch.cat([img_idx, classes, bboxes], dim=-1).float()
+    model.load_state_dict(sd, strict=True)
+    model.train(True)
+    lf = R.ComputeLoss(model)
+    with torch.no_grad():
+        o = model(images.clone())
+        loss = lf(o, labels, None)
+    out = {"labels": labels.numpy(), "loss": np.array(float(loss)), "img_sum": np.array(float(images.double().sum())),
+           "img_sample": images.reshape(-1)[::4801].numpy().copy()}
+    for i in range(3):
+        flat = o[i].reshape(-1).numpy()
+        step = max(1, flat.size // 4096)
+        out[f"o{i}_sample"] = flat[::step][:4096].copy()
+        out[f"o{i}_step"] = np.array(step)
+    model.train(False)
+    model.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        oe = model(images.clone())
+        boxes = R.cells_to_bboxes(oe, model.head.anchors, model.head.stride, is_pred=True, to_list=False)
+        kept = R.non_max_suppression(boxes, iou_threshold=0.6, threshold=0.01, max_detections=300, tolist=True)
+    out["eval_nms_counts"] = np.array([len(k) for k in kept])
+    out["eval_nms_first"] = np.array(kept[0][:20], np.float32).reshape(-1, 6)
+    out["eval_obj_sample"] = boxes[0, ::97, 1].numpy().copy()
+    save("g10_config0", **out)
+
+
 def g7_large_step(model):
     """first train-mode forward + ComputeLoss of the reference at a batch large enough that every layer width
     runs its multi-workgroup reductions (B=16 @ 320x320): the loss and its 3 components, and sampled logits"""
@@ -382,7 +419,7 @@ def g8_input_stage():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -394,3 +431,4 @@ if __name__ == "__main__":
     if "g7" in which: g7_large_step(model)
     if "g8" in which: g8_input_stage()
     if "g9" in which: g9_nms_aladdin()
+    if "g10" in which: g10_config0(model)

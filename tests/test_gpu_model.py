@@ -277,3 +277,35 @@ def test_native_optimizer_state_is_torch_adam_state():
     assert int(nat3.d_step.item()) == 3
     ref_m = torch.cat([opt.state_dict()["state"][i]["exp_avg"].reshape(-1) for i in range(len(list(m1.parameters())))])
     np.testing.assert_allclose(nat3.m.cpu().numpy(), ref_m.cpu().numpy(), rtol=0, atol=0)
+
+
+def test_config0_reference_recipe_golden(golden):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case (my_loss_vs_ultra_loss.py:26-33:
+    seed 355, 4x3x640x640 uniform images, 12 labels): train-mode logits + ComputeLoss in f32 against the real
+    reference, and the detect path (eval forward, decode, NMS at 0.01 / 0.6 / 300) end to end"""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    from yolov5m_amd.utils.bboxes_utils import non_max_suppression
+    g = golden("g10_config0")
+    torch.manual_seed(355)
+    images = torch.rand((4, 3, 640, 640))
+    np.testing.assert_allclose(images.reshape(-1)[::4801].numpy(), g["img_sample"], rtol=0, atol=0)   # same inputs
+    x = images.to(DEV)
+    labels = torch.from_numpy(g["labels"])
+    m = _model("f32"); m.train()
+    with torch.no_grad():
+        o = m(x)
+    for i in range(3):
+        got = o[i].reshape(-1).cpu().numpy()[::int(g[f"o{i}_step"])][:4096]
+        ref = g[f"o{i}_sample"]
+        assert np.abs(got - ref).max() <= TRAIN_TOL["s320"] * np.abs(ref).max(), (i, np.abs(got - ref).max())
+    m2 = _model("f32"); m2.train()
+    loss = ComputeLoss(m2)(m2(x), labels, None)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-4)
+    m3 = _model("f32"); m3.eval()
+    with torch.no_grad():
+        oe = m3(x)
+        boxes = cells_to_bboxes(oe, m3.head.anchors, m3.head.stride, is_pred=True, to_list=False)
+        kept = non_max_suppression(boxes, iou_threshold=0.6, threshold=0.01, max_detections=300, tolist=True)
+    assert [len(k) for k in kept] == g["eval_nms_counts"].tolist()
+    np.testing.assert_allclose(boxes[0, ::97, 1].cpu().numpy(), g["eval_obj_sample"], rtol=1e-4, atol=1e-5)
