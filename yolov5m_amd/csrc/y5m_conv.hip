@@ -11,13 +11,14 @@
 // BNR  = true : data-gradient launch that is the LAST writer of a CBL output gradient: the epilogue also emits
 //             the BatchNorm-backward reduction partials (y5m_conv_args.bn_part), see include/y5m.h
 template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR>
-__global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams P) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams P) {
+    constexpr int THREADS = WM * WN * 64, RSTEP = THREADS / 8;   // RSTEP: tile rows staged per pass (8 chunks per row)
     constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
-    static_assert(BM == CV_BM && WM * WN == 4, "tile config");
+    static_assert(BM == CV_BM && (WM * WN == 4 || WM * WN == 8), "tile config");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    constexpr int NA = BM * 8 / CV_THREADS;                       // 16-byte chunks per thread (A)
-    constexpr int NB = (BN * 8 + CV_THREADS - 1) / CV_THREADS;    // (B)
+    constexpr int NA = BM * 8 / THREADS;                          // 16-byte chunks per thread (A)
+    constexpr int NB = (BN * 8 + THREADS - 1) / THREADS;          // (B)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
     const unsigned rowb = (unsigned)(P.ldin * ESZ);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RSTEP * i;
         int pv = m, yv = 0, xv = 0;
         if (!lin_in) {
             int gx, t, gy, b;
@@ -81,11 +82,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         ta = tap / P.tw;
         tb = tap - ta * P.tw;
     }
-    // weight rows r0 + 32*i of this channel tile: loop-invariant offsets, the K position is an SGPR offset
+    // weight rows r0 + RSTEP*i of this channel tile: loop-invariant offsets, the K position is an SGPR offset
     unsigned wb_off[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int r = r0 + 32 * i;
+        const int r = r0 + RSTEP * i;
         wb_off[i] = (unsigned)(((size_t)(n0 + (r < BN ? r : 0)) * P.Kp + q * CH) * ESZ);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
         unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(As + lds_off(r0 + 32 * i, q)) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(As + lds_off(r0 + RSTEP * i, q)) = ra[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            if (r0 + 32 * i < BN) *reinterpret_cast<u32x4*>(Bs + lds_off(r0 + 32 * i, q)) = rb[i];
+            if (r0 + RSTEP * i < BN) *reinterpret_cast<u32x4*>(Bs + lds_off(r0 + RSTEP * i, q)) = rb[i];
     };
 
     f32x4 acc[NF][MF];
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
             }
         }
         __syncthreads();
-        for (int tt = tid; tt < 2 * BN; tt += CV_THREADS) {
+        for (int tt = tid; tt < 2 * BN; tt += THREADS) {
             const int which = tt / BN, nl = tt - which * BN;
             float t = 0.f;
 #pragma unroll
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm_kernel(const ConvParams
             }
         }
         __syncthreads();
-        for (int tt = tid; tt < 2 * BN; tt += CV_THREADS) {
+        for (int tt = tid; tt < 2 * BN; tt += THREADS) {
             const int which = tt / BN, nl = tt - which * BN;
             float t = 0.f;
 #pragma unroll
@@ -356,7 +357,7 @@ static int launch_conv_db(ConvParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(CV_THREADS), lds, st, P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(WM * WN * 64), lds, st, P);
     Y5M_CHECK_LAUNCH("conv_igemm_kernel");
     return Y5M_OK;
 }
@@ -364,6 +365,7 @@ static int launch_conv_db(ConvParams& P, hipStream_t st) {
 // Channel tile: 48 for the 48-channel layers, 192 (wave tile 64x96: half the LDS bytes per MFMA of the
 // 96 tile) when N is a multiple of 192, else 96. Y5M_CONV_BN192=0 disables the wide tile (A/B runs).
 static int g_bn192 = -1;
+static int g_w8 = -1;      // Y5M_CONV_W8: 8-wave workgroups (0 off, 1 the 192-channel tile, 2 also the 96-channel tile)
 static int g_sbuf_kt = -1;   // K steps up to which the single-buffer variant is used (Y5M_CONV_SBUF_KT, default 6)
 template <typename T, int WM, int WN, int MF, int NF>
 static int launch_conv(ConvParams& P, hipStream_t st) {
@@ -399,7 +401,15 @@ static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
     if (P.epi == EPI_DGRAD && P.bn_part && BN == 192) BN = 96;     // fused BN-backward partials: 96-channel tile
     if (dtype == Y5M_BF16) {
         if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
-        if (BN == 192) return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
+        if (BN == 192) {
+            // Y5M_CONV_W8=1: the same 128x192 tile with 8 waves (64x48 wave tiles): twice the waves per SIMD to
+            // hide barrier / LDS / load waits, 40 % more LDS reads per MFMA (A/B knob)
+            if (g_w8 < 0) { const char* e = getenv("Y5M_CONV_W8"); g_w8 = e ? atoi(e) : 1; }
+            if (g_w8) return launch_conv<bf16_t, 2, 4, 4, 3>(P, st);
+            return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
+        }
+        if (g_w8 < 0) { const char* e = getenv("Y5M_CONV_W8"); g_w8 = e ? atoi(e) : 1; }
+        if (g_w8 >= 2) return launch_conv<bf16_t, 4, 2, 2, 3>(P, st);      // 128x96 tile, 8 waves of 32x48
         return launch_conv<bf16_t, 2, 2, 4, 3>(P, st);
     } else {
         if (BN == 48) return launch_conv<float, 4, 1, 2, 3>(P, st);

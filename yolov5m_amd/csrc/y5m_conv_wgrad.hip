@@ -49,7 +49,8 @@ struct WgCfg {
     static constexpr int LDX = BF ? TC : TC + 16;
     static constexpr int YB = BF ? (KCH / 32) * (TN / 16) * WG_SUB : KCH * LDY * 4;   // bytes of the dY tile
     static constexpr int XB = BF ? (KCH / 32) * (TC / 16) * WG_SUB : KCH * LDX * 4;
-    static constexpr int TPP = WG_THREADS / KCH;       // threads per pixel row of a chunk
+    static constexpr int THREADS = WN * WC * WK * 64;  // 4 waves, or 8 for the wide 8-wave tile
+    static constexpr int TPP = THREADS / KCH;          // threads per pixel row of a chunk
     static constexpr int YCPR = TN / CH, XCPR = TC / CH;   // 16-byte chunks per pixel row
     static constexpr int NLDY = (YCPR + TPP - 1) / TPP;
     static constexpr int NLDX = (XCPR + TPP - 1) / TPP;
@@ -66,7 +67,7 @@ __device__ __forceinline__ int lds_chunk_off(int pl, int cc, int tile_ch, int ld
 }
 
 template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams P) {
+__global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradParams P) {
     using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR>;
     constexpr int KCH = C::KCH, CH = C::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -301,7 +302,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         // layers when the count dropped from 522 to <= 512); capacity = blocks per CU (LDS / VGPR limited:
         // 2 for the 96x48 wave tile, 3 otherwise) x 256 CUs. The 48x16 stem tile (one tap per block) wants more.
         const int per_cu = (int)((160 * 1024) / (2 * (size_t)(C::YB + C::XB)));
-        const int resident = 256 * (NFR == 6 ? 2 : (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu)));
+        const int resident = 256 * ((NFR == 6 || C::THREADS > 256) ? 2 : (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu)));
         int ks;
         if (target > 0) ks = (target + base - 1) / base;
         else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
@@ -317,7 +318,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     auto kern = wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, st, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
     Y5M_CHECK_LAUNCH("wgrad_kernel");
     return Y5M_OK;
 }
@@ -340,6 +341,7 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     static int big = -1;
     if (big < 0) { const char* e = getenv("Y5M_WGRAD_BIG"); big = e ? atoi(e) : 1; }
     if (big == 2 && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6>(P, st);
+    if (big == 3 && P.N % 192 == 0) return launch_wgrad<T, 4, 2, 1, 3, 1, 3>(P, st);        // 192 x 96, 8 waves of 48 x 48
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
 }
