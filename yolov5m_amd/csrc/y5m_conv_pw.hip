@@ -222,7 +222,7 @@ static int g_pw_occ = -1;      // Y5M_CONV_PW_OCC: workgroups per CU of the pers
 template <int NCF, int KS, int EPI, bool OLD, bool BNR = false>
 static int launch_pw(const ConvParams& P, hipStream_t st) {
     constexpr int NC = NCF * 16;
-    if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 2; }
+    if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 4; }
     const int nchunks = P.N / NC;
     const int ngroups = (P.M + 15) / 16;
     const int stat_rows = (P.M + CV_BM - 1) / CV_BM;                 // rows the caller sized the stats buffer for

@@ -66,7 +66,8 @@ __device__ __forceinline__ int lds_chunk_off(int pl, int cc, int tile_ch, int ld
     }
 }
 
-template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR>
+// SB: ONE LDS buffer (two barriers per chunk, half the LDS -> more resident blocks) instead of two
+template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR, bool SB>
 __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradParams P) {
     using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR>;
     constexpr int KCH = C::KCH, CH = C::CH;
@@ -260,9 +261,15 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
             const bool more = chk + 1 < ch_hi;
             if (more) load_chunk();
             compute(cur);
-            if (more) store_chunk(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+            if constexpr (SB) {
+                __syncthreads();                     // every wave is done reading the only buffer
+                if (more) store_chunk(0);
+                __syncthreads();
+            } else {
+                if (more) store_chunk(cur ^ 1);
+                __syncthreads();
+                cur ^= 1;
+            }
         }
         // D[n][c]: lane owns n = (lane>>4)*4 + r, c = lane&15 -> atomics coalesced along c
         const int i = lane & 15, g = lane >> 4;
@@ -301,6 +308,8 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         // blocks <= resident capacity (a second, nearly empty round cost 20 %: 137 -> 111 us on the 192x192
         // layers when the count dropped from 522 to <= 512); capacity = blocks per CU (LDS / VGPR limited:
         // 2 for the 96x48 wave tile, 3 otherwise) x 256 CUs. The 48x16 stem tile (one tap per block) wants more.
+        static int sbk = -1;
+        if (sbk < 0) { const char* e = getenv("Y5M_WGRAD_SB"); sbk = e ? atoi(e) : 1; }
         const int per_cu = (int)((160 * 1024) / (2 * (size_t)(C::YB + C::XB)));
         const int resident = 256 * ((NFR == 6 || C::THREADS > 256) ? 2 : (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu)));
         int ks;
@@ -308,16 +317,23 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
         else if (taps == 1) ks = (320 + base - 1) / base;
         else if (C::TC <= 16) ks = (2048 + base - 1) / base;
-        else ks = resident / base;                          // floor: never more blocks than fit at once
+        else ks = (sbk && NFR != 6 && C::THREADS == 256 ? 1024 : resident) / base;   // floor: never more blocks than fit at once (SB: 4 per CU)
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
         P.ksplit = ks < 1 ? 1 : ks;
     }
-    const size_t lds = 2 * (size_t)(C::YB + C::XB);
+    static int sb = -1;                                   // single LDS buffer (default; Y5M_WGRAD_SB=0: double buffer): in the full step -0.15 ms
+    if (sb < 0) { const char* e = getenv("Y5M_WGRAD_SB"); sb = e ? atoi(e) : 1; }
+    const bool use_sb = sb && TPB == 1;
+    const size_t lds = (use_sb ? 1 : 2) * (size_t)(C::YB + C::XB);
     const unsigned grid = (unsigned)(P.tiles_n * P.tiles_c * taps * P.ksplit);
-    auto kern = wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR>;
+    auto kern = use_sb ? wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true> : wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::YB + C::XB));
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (C::YB + C::XB)));
+        attr = true;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
     Y5M_CHECK_LAUNCH("wgrad_kernel");
     return Y5M_OK;
