@@ -605,7 +605,7 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     w += y5m_align((size_t)2 * C * 4);
     float* stage = reinterpret_cast<float*>(w);
     hipStream_t st = y5m_stream(stream);
-    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX);
+    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX);            // (swept 256..2048 in the full step: 512 is best)
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(256), 0, st,
                                          (const T*)dz, lddz, (const T*)y, ldy, scale, shift, M, C, gr.CG, gr.RP, act, part);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
