@@ -315,7 +315,11 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         int ks;
         if (target > 0) ks = (target + base - 1) / base;
         else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
-        else if (taps == 1) ks = (320 + base - 1) / base;
+        else if (taps == 1) {
+            static int pwb = -1;                            // Y5M_WGRAD_PW_BLOCKS: blocks of a pointwise weight gradient
+            if (pwb < 0) { const char* e = getenv("Y5M_WGRAD_PW_BLOCKS"); pwb = e ? atoi(e) : 160; }   // (swept 128..768 inside the full step: atomics-bound, fewer is better)
+            ks = (pwb + base - 1) / base;
+        }
         else if (C::TC <= 16) ks = (2048 + base - 1) / base;
         else ks = (sbk && NFR != 6 && C::THREADS == 256 ? 1024 : resident) / base;   // floor: never more blocks than fit at once (SB: 4 per CU)
         const int maxks = (chunks + minch - 1) / minch;
