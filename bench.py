@@ -167,7 +167,10 @@ def main():
     hook = parallel.GradAllReduce(world) if world > 1 else None
     step = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook)
 
-    images = synth_images(B, S, S, seed=f"img/rank{rank}").to(dev)     # resident in HBM before timing
+    # inputs resident in HBM before timing: the batch is written once into the step's static input buffer (what a
+    # device-side loader / y5m_preprocess_u8 does), so step() makes no further copy of the images
+    images = step.input_buffer(B, S, S)
+    images.copy_(synth_images(B, S, S, seed=f"img/rank{rank}").to(dev))
     targets = synth_labels(B, 8, seed=f"lab/rank{rank}").to(dev)
 
     for _ in range(max(args.warmup, 1)):

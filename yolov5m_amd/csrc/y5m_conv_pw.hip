@@ -223,11 +223,14 @@ template <int NCF, int KS, int EPI, bool OLD, bool BNR = false>
 static int launch_pw(const ConvParams& P, hipStream_t st) {
     constexpr int NC = NCF * 16;
     if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 4; }
+    static int occ_fwd = -1;       // forward launches run alone on the GPU, backward ones next to the weight gradient
+    if (occ_fwd < 0) { const char* e = getenv("Y5M_CONV_PW_OCC_FWD"); occ_fwd = e ? atoi(e) : g_pw_occ; }
+    const int occ = EPI == EPI_DGRAD ? g_pw_occ : occ_fwd;
     const int nchunks = P.N / NC;
     const int ngroups = (P.M + 15) / 16;
     const int stat_rows = (P.M + CV_BM - 1) / CV_BM;                 // rows the caller sized the stats buffer for
     // stream blocks (4 streams each): every CU gets g_pw_occ workgroups, in multiples of 8 per chunk (XCD mapping)
-    int sblocks = 256 * g_pw_occ / nchunks / 8 * 8;
+    int sblocks = 256 * occ / nchunks / 8 * 8;
     if (sblocks < 8) sblocks = 8;
     const int need = (ngroups + 3) / 4;
     if (sblocks > (need + 7) / 8 * 8) sblocks = (need + 7) / 8 * 8;

@@ -182,7 +182,8 @@ class NativeTrainStep:
 
     def load_inputs(self, images, targets):
         eng = self.model._engine_for(images)
-        eng.x_in.copy_(images, non_blocking=True)
+        if images.data_ptr() != eng.x_in.data_ptr():       # a loader that fills input_buffer() directly skips this copy
+            eng.x_in.copy_(images, non_blocking=True)
         nt = int(targets.shape[0])
         if nt > self.nt_max:
             raise _lib.Y5MError(f"nt={nt} exceeds nt_max={self.nt_max}")
@@ -190,6 +191,12 @@ class NativeTrainStep:
             self.targets[:nt].copy_(targets.reshape(-1, 6).float(), non_blocking=True)
         self.d_nt.fill_(nt)
         return eng
+
+    def input_buffer(self, B, H, W):
+        """the engine's static (B,3,H,W) float32 input tensor for this shape: a data loader (or preprocess_u8 with
+        out=...) can write the batch straight into it; step() then makes no device-to-device copy of the images"""
+        probe = torch.empty((B, 3, H, W), dtype=torch.float32, device="meta")
+        return self.model._engine_for(probe).x_in
 
     def step(self, images, targets):
         """Returns the device tensor [loss*bs, lbox, lobj, lcls] of THIS step (no host sync).
