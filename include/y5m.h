@@ -204,8 +204,16 @@ typedef struct {
     int32_t ksplit;      /* pixel-range splits (<=0: library picks)                              */
     int32_t tiles_n, tiles_c;   /* filled by the library                                         */
     const void* zeros;   /* >= 16 zero bytes in device memory (see y5m_conv_args)                 */
+    int32_t slices_cap;  /* 0: split-K partial tiles are ADDED into dwgt [N][lddw] with f32 atomics (dwgt zeroed by the
+                            caller). > 0: NON-ATOMIC mode: dwgt holds slices_cap slices of N*lddw floats and pixel
+                            range k writes its partial tile into slice k with plain stores (no zeroing needed, at most
+                            slices_cap ranges); y5m_unpack_wgrad_slices sums the slices in a fixed order. Pointwise
+                            layers are bound by the atomics otherwise (their output tiles are tiny). */
+    int32_t pad_;
 } y5m_wgrad_args;
 int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
+/* the number of pixel ranges (= slices written in non-atomic mode) y5m_wgrad will use for these arguments */
+int y5m_wgrad_slices(const y5m_wgrad_args* args, int dtype);
 
 /* Weight layout conversion. master f32 [Cout][Cin][KH][KW] (the reference state_dict layout,
  * model.py:15) -> packed K-contiguous rows in compute dtype.
@@ -229,6 +237,10 @@ int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t tota
 /* packed f32 gradient [Cout][ldg] (mode 0 or 2 ordering) -> [Cout][Cin][KH][KW] */
 int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
                      void* stream);
+/* the same from `nslices` partial gradients laid out slice_stride floats apart (non-atomic y5m_wgrad), summed in
+ * slice order */
+int y5m_unpack_wgrad_slices(const float* gp, int nslices, int64_t slice_stride, int Cout, int Cin, int KH, int KW, int mode,
+                            int ldg, float* dst, void* stream);
 /* Input stage on the device (utils/training_utils.py:98 `images.float()/255` and :11-28 multi_scale):
  * uint8 (B,3,Hs,Ws) -> f32 (B,3,H,W) = F.interpolate(img/255, (H,W), "bilinear", align_corners=False);
  * Hs==H && Ws==W is the plain /255 conversion. */

@@ -370,3 +370,24 @@ def test_conv_dgrad_fused_bn_reduction(case, dtype, src):
     r1, r2 = dt.sum((0, 2, 3)), (dt * yy).sum((0, 2, 3))
     np.testing.assert_allclose(s1.cpu().numpy(), r1.float().numpy(), rtol=2e-3, atol=2e-2)
     np.testing.assert_allclose(s2.cpu().numpy(), r2.float().numpy(), rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [CONV_CASES[2], CONV_CASES[5], CONV_CASES[7], (2, 48, 48, 50, 48, 1, 1, 0),
+                                  (2, 96, 48, 50, 48, 1, 1, 0), (2, 48, 48, 50, 96, 1, 1, 0), (2, 192, 40, 40, 192, 1, 1, 0),
+                                  CONV_CASES[0]])
+def test_conv_wgrad_non_atomic_slices(case, dtype):
+    """non-atomic split-K (one partial slice per pixel range and K-wave, NaN-filled beforehand: every element of every
+    slice must be written), summed in a fixed order by the unpack: every tile configuration incl. the K-wave ones"""
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    x = _q(_rand((B, Cin, H, W), 21), dtype)
+    w = _rand((Cout, Cin, k, k), 22, -0.2, 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = _q(_rand(tuple(y.shape), 23), dtype)
+    y.backward(dy)
+    got = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, dtype, slices=True).cpu()
+    assert bool(torch.isfinite(got).all())
+    assert _relerr(got, w.grad) < TOL[dtype], (case, dtype, _relerr(got, w.grad))
+    again = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, dtype, slices=True).cpu()
+    assert torch.equal(got, again)                      # fixed summation order: bit-reproducible

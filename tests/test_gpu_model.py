@@ -85,6 +85,7 @@ def test_train_step_grads_f32_golden(golden, variant, monkeypatch):
     from yolov5m_amd.ultralytics_loss import ComputeLoss
     if variant == "bnred_all":
         monkeypatch.setenv("Y5M_BNRED", "all")
+        monkeypatch.setenv("Y5M_WGRAD_SLICES", "1")       # and the non-atomic pointwise weight gradients
     elif variant == "unfused":
         monkeypatch.setenv("Y5M_MERGE_C3", "0"); monkeypatch.setenv("Y5M_LAZY_RES", "0"); monkeypatch.setenv("Y5M_OVERLAP", "0")
     g = golden("g5_model")

@@ -44,7 +44,7 @@ class WgradArgs(ctypes.Structure):
     _fields_ = ([("dy", c_void_p), ("x", c_void_p), ("dwgt", c_void_p)] +
                 [(n, c_int) for n in ("B", "Hin", "Win", "ldx", "Hg", "Wg", "sy", "sx", "th", "tw", "dh0", "dhs",
                                       "dw0", "dws", "C", "N", "M", "lddy", "lddw", "ksplit", "tiles_n", "tiles_c")] +
-                [("zeros", c_void_p)])
+                [("zeros", c_void_p), ("slices_cap", c_int), ("pad_", c_int)])
 
 
 _zero_pages = {}
@@ -104,6 +104,8 @@ _SIGS = {
     "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y5m_pack_weights_batched": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "y5m_wgrad_slices": (c_int, [c_void_p, c_int]),
+    "y5m_unpack_wgrad_slices": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y5m_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

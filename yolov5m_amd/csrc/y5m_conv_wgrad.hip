@@ -252,6 +252,7 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
         }
     };
 
+    const bool slices = P.slices_cap > 0;          // non-atomic mode: every pixel range writes its own slice (even an empty one)
     if (ch_lo < ch_hi) {
         load_chunk();
         store_chunk(0);
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
                 cur ^= 1;
             }
         }
+    }
+    if (ch_lo < ch_hi || slices) {
         // D[n][c]: lane owns n = (lane>>4)*4 + r, c = lane&15 -> atomics coalesced along c
         const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -284,11 +287,18 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + wn * (16 * NFR) + a * 16 + g * 4 + r;
-                    if (n < P.N) atomicAdd(P.dwgt + (size_t)n * P.lddw + tap * P.C + c, acc[a][b][r]);
+                    if (n < P.N) {
+                        float* d = P.dwgt + (size_t)n * P.lddw + tap * P.C + c;
+                        if (slices) d[(size_t)(ksp * WK + wk) * P.N * P.lddw] = acc[a][b][r];   // one slice per (range, K-wave)
+                        else atomicAdd(d, acc[a][b][r]);
+                    }
                 }
             }
     }
 }
+
+static thread_local bool g_plan_only = false;   // y5m_wgrad_slices: run the dispatch + split-K sizing, launch nothing
+static thread_local int g_plan_slices = 0;
 
 template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3>
 static int launch_wgrad(WgradParams& P, hipStream_t st) {
@@ -315,6 +325,11 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         int ks;
         if (target > 0) ks = (target + base - 1) / base;
         else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
+        else if (taps == 1 && P.slices_cap > 0) {
+            static int pws = -1;                            // Y5M_WGRAD_PW_SLICE_BLOCKS: non-atomic mode is not atomics-bound
+            if (pws < 0) { const char* e = getenv("Y5M_WGRAD_PW_SLICE_BLOCKS"); pws = e ? atoi(e) : 384; }
+            ks = (pws + base - 1) / base;
+        }
         else if (taps == 1) {
             static int pwb = -1;                            // Y5M_WGRAD_PW_BLOCKS: blocks of a pointwise weight gradient
             if (pwb < 0) { const char* e = getenv("Y5M_WGRAD_PW_BLOCKS"); pwb = e ? atoi(e) : 160; }   // (swept 128..768 inside the full step: atomics-bound, fewer is better)
@@ -326,6 +341,12 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         ks = ks > maxks ? maxks : ks;
         P.ksplit = ks < 1 ? 1 : ks;
     }
+    if (P.slices_cap > 0) {
+        if (P.ksplit * WK > P.slices_cap) P.ksplit = P.slices_cap / WK;
+        if (P.ksplit < 1) { y5m_set_error("y5m_wgrad: slices_cap smaller than the K-waves of the tile"); return Y5M_EINVAL; }
+    }
+    g_plan_slices = P.ksplit * WK;
+    if (g_plan_only) return Y5M_OK;
     static int sb = -1;                                   // single LDS buffer (default; Y5M_WGRAD_SB=0: double buffer): in the full step -0.15 ms
     if (sb < 0) { const char* e = getenv("Y5M_WGRAD_SB"); sb = e ? atoi(e) : 1; }
     const bool use_sb = sb && TPB == 1;
@@ -364,6 +385,14 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     if (big == 3 && P.N % 192 == 0) return launch_wgrad<T, 4, 2, 1, 3, 1, 3>(P, st);        // 192 x 96, 8 waves of 48 x 48
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
+}
+
+extern "C" int y5m_wgrad_slices(const y5m_wgrad_args* args, int dtype) {
+    g_plan_only = true;
+    g_plan_slices = 0;
+    const int rc = y5m_wgrad(args, dtype, nullptr);
+    g_plan_only = false;
+    return rc == Y5M_OK ? g_plan_slices : rc;
 }
 
 extern "C" int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream) {

@@ -133,8 +133,8 @@ extern "C" int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, i
 }
 
 // packed weight gradient f32 [N][taps][Cc] -> reference layout [Cout][Cin][KH][KW] (mode as above)
-__global__ void unpack_wgrad_kernel(const float* __restrict__ gp, int Cout, int Cin, int KH, int KW, int mode,
-                                    int ldg, float* __restrict__ dst) {
+__global__ void unpack_wgrad_kernel(const float* __restrict__ gp, int nslices, int64_t slice_stride, int Cout, int Cin,
+                                    int KH, int KW, int mode, int ldg, float* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)Cout * Cin * KH * KW;
     if (i >= n) return;
@@ -150,14 +150,27 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ gp, int Cout, int 
     } else {
         k = (kh * KW + kw) * Cin + ci;
     }
-    dst[i] = gp[(size_t)co * ldg + k];
+    const float* p = gp + (size_t)co * ldg + k;
+    float v = p[0];
+    for (int sidx = 1; sidx < nslices; ++sidx) v += p[(size_t)sidx * slice_stride];     // fixed order: deterministic
+    dst[i] = v;
 }
 
 extern "C" int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
                                 void* stream) {
     const int64_t n = (int64_t)Cout * Cin * KH * KW;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), gp, Cout, Cin, KH,
-                       KW, mode, ldg, dst);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), gp, 1, (int64_t)0, Cout,
+                       Cin, KH, KW, mode, ldg, dst);
+    Y5M_CHECK_LAUNCH("unpack_wgrad_kernel");
+    return Y5M_OK;
+}
+
+extern "C" int y5m_unpack_wgrad_slices(const float* gp, int nslices, int64_t slice_stride, int Cout, int Cin, int KH, int KW,
+                                       int mode, int ldg, float* dst, void* stream) {
+    Y5M_REQUIRE(nslices >= 1, "nslices");
+    const int64_t n = (int64_t)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), gp, nslices, slice_stride,
+                       Cout, Cin, KH, KW, mode, ldg, dst);
     Y5M_CHECK_LAUNCH("unpack_wgrad_kernel");
     return Y5M_OK;
 }

@@ -110,7 +110,11 @@ class Engine:
         # BN -1.1: the silu' + two FMAs + y read per element that a purely HBM-bound reduce pass does for free
         # are NOT free in a conv epilogue (the pointwise kernel turns VALU-bound). Kept as a tested option.
         self.bnred = {"0": False, "all": "all"}.get(os.environ.get("Y5M_BNRED", "0"), True)
-        self.merge_c3 = os.environ.get("Y5M_MERGE_C3", "1") != "0"          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
+        self.merge_c3 = os.environ.get("Y5M_MERGE_C3", "1") != "0"
+        # pointwise weight gradients without atomics: one partial slice per pixel range, summed by the unpack in a
+        # fixed order (bit-reproducible). OFF by default: measured 32.6 vs 31.2 ms/step -- the slice traffic (N x C x 4
+        # bytes per pixel range, up to 2.4 MB for the 768-channel layers) costs more than the L2 atomics it replaces.
+        self.wgrad_slices = os.environ.get("Y5M_WGRAD_SLICES", "0") != "0"          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
         self._bwd_stack = []
         self.layers = []
         self._scratch_elems = 0
@@ -301,11 +305,8 @@ class Engine:
             # stream, concurrently with this layer's data gradient and the next layer's BN backward:
             # wgrad is HBM/atomic-bound, dgrad MFMA-bound, and neither fills the chip alone
             mode = 2 if lay.stem else 0
-            f_wg = lambda wa=wa: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad")
-            f_up = lambda: _lib.check(
-                L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, lay.cout, lay.cin_real, lay.k, lay.k, mode,
-                                   lay.ldgw, _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad")
-            ops.append((self._side_op([f_wg, f_up], slot), ()))
+            ops.append((self._side_op(self._wgrad_ops(lay, wa, [(0, lay.cout, lay.cin_real, lay.k, mode, P["gw"].data_ptr())]),
+                                      slot), ()))
             self._grad_done.append((lay.name, P["gw"].data_ptr()))
             # data gradient
             if need_dx:
@@ -412,6 +413,32 @@ class Engine:
             L.y5m_bn_bwd(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                          bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr,
                          lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ())
+
+    def _wgrad_ops(self, lay, wa, unpacks):
+        """launch closures [wgrad, unpack...] of one weight gradient. unpacks: [(row offset, Cout, Cin, k, mode,
+        dst flat-gradient pointer)]. Pointwise layers use the non-atomic slices mode (y5m_wgrad_args.slices_cap): their
+        own buffer, no zeroing, deterministic sum; 3x3 layers accumulate with atomics into the zeroed self.gw."""
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        fs = [lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad")]
+        use_slices = self.wgrad_slices and wa.th == 1 and wa.tw == 1
+        if use_slices:
+            wa.slices_cap = 4096
+            ns = L.y5m_wgrad_slices(ctypes.byref(wa), dt)
+            if ns < 1:
+                raise _lib.Y5MError("y5m_wgrad_slices failed")
+            stride = wa.N * wa.lddw
+            lay.gw_slices = torch.zeros((ns * stride,), dtype=torch.float32, device=self.dev)
+            wa.dwgt, wa.slices_cap = lay.gw_slices.data_ptr(), ns
+            for (row0, cout, cin, k, mode, dst) in unpacks:
+                fs.append(lambda row0=row0, cout=cout, cin=cin, k=k, mode=mode, dst=dst: _lib.check(
+                    L.y5m_unpack_wgrad_slices(lay.gw_slices.data_ptr() + 4 * row0 * wa.lddw, ns, stride, cout, cin, k, k, mode,
+                                              wa.lddw, dst, st()), "y5m_unpack_wgrad_slices"))
+        else:
+            for (row0, cout, cin, k, mode, dst) in unpacks:
+                fs.append(lambda row0=row0, cout=cout, cin=cin, k=k, mode=mode, dst=dst: _lib.check(
+                    L.y5m_unpack_wgrad(wa.dwgt + 4 * row0 * wa.lddw, cout, cin, k, k, mode, wa.lddw, dst, st()),
+                    "y5m_unpack_wgrad"))
+        return fs
 
     def _flush_lazy(self, act):
         """ops that materialise a pending lazy gradient of `act` (grad = lazy source): a copy. Called by every
@@ -525,11 +552,7 @@ class Engine:
             wa.Hg, wa.Wg, wa.sy, wa.sx = x.H, x.W, 1, 1
             wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
             wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = K, N2, M, N2, K, 0
-            fs = [lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(pair)")]
-            for lay, P in halves:
-                fs.append(lambda lay=lay, P=P: _lib.check(
-                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * (gw_off + lay.off * K), cout, K, 1, 1, 0, K,
-                                       _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(pair)"))
+            fs = self._wgrad_ops(halves[0][0], wa, [(lay.off, cout, K, 1, 0, P["gw"].data_ptr()) for lay, P in halves])
             ops.append((self._side_op(fs, slot), ()))
             for lay, P in halves:
                 self._grad_done.append((lay.name, P["gw"].data_ptr()))
@@ -653,11 +676,7 @@ class Engine:
                 wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
                 wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = x.C, ldp, M, ldp, x.C, 0
                 lay.wgrad_args = wa
-                f_wg = lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad(head)")
-                f_up = lambda: _lib.check(
-                    L.y5m_unpack_wgrad(self.gw.data_ptr() + 4 * lay.gw_off, N, x.C, 1, 1, 0, lay.ldgw,
-                                       _lib.ptr(P["gw"]), st()), "y5m_unpack_wgrad(head)")
-                ops.append((self._side_op([f_wg, f_up], slot), ()))
+                ops.append((self._side_op(self._wgrad_ops(lay, wa, [(0, N, x.C, 1, 0, P["gw"].data_ptr())]), slot), ()))
                 self._grad_done.append((lay.name, P["gw"].data_ptr()))
                 self._written(x)
                 acc = 1 if x.gw else 0

@@ -179,8 +179,9 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=N
     return from_nhwc(dx)
 
 
-def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0):
-    """dy (B,Cout,Ho,Wo), x (B,Cin,H,W) -> dw (Cout,Cin,k,k): autograd of conv2d wrt its weight."""
+def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0, slices=False):
+    """dy (B,Cout,Ho,Wo), x (B,Cin,H,W) -> dw (Cout,Cin,k,k): autograd of conv2d wrt its weight.
+    slices: the non-atomic mode (one partial gradient slice per pixel range, summed by the unpack)."""
     L = _lib.lib()
     dt, tdt, CH, BK = _DT[dtype]
     B, Cout, Ho, Wo = dy.shape
@@ -194,8 +195,19 @@ def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0):
     a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
     a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
     a.C, a.N, a.M, a.lddy, a.lddw, a.ksplit = Cin, Cout, B * Ho * Wo, Cout, k * k * Cin, ksplit
-    _lib.check(L.y5m_wgrad(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_wgrad")
     out = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=dy.device)
+    if slices:
+        a.slices_cap = 4096
+        ns = L.y5m_wgrad_slices(ctypes.byref(a), dt)
+        assert ns >= 1, _lib.last_error() if hasattr(_lib, "last_error") else ns
+        gp = torch.full((ns, Cout, k * k * Cin), float("nan"), dtype=torch.float32, device=dy.device)   # no zeroing needed
+        a.dwgt, a.slices_cap = gp.data_ptr(), ns
+        _lib.check(L.y5m_wgrad(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_wgrad")
+        _lib.check(L.y5m_unpack_wgrad_slices(_lib.ptr(gp), ns, Cout * k * k * Cin, Cout, Cin, k, k, 0, k * k * Cin,
+                                             _lib.ptr(out), _lib.stream_ptr()), "y5m_unpack_wgrad_slices")
+        torch.cuda.synchronize()
+        return out
+    _lib.check(L.y5m_wgrad(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_wgrad")
     _lib.check(L.y5m_unpack_wgrad(_lib.ptr(gp), Cout, Cin, k, k, 0, k * k * Cin, _lib.ptr(out), _lib.stream_ptr()),
                "y5m_unpack_wgrad")
     torch.cuda.synchronize()
