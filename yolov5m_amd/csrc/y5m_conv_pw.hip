@@ -92,7 +92,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
         const size_t p = (size_t)g * 16 + fr;
         const ptrdiff_t off = (ptrdiff_t)(p * P.ldin + fq * 8);
 #pragma unroll
-        for (int s = 0; s < KS - 1; ++s) xr[s] = *reinterpret_cast<const u32x4*>(X + off + s * 32);
+        for (int s = 0; s < KS - 1; ++s) xr[s] = *reinterpret_cast<const u32x4*>(X + off + s * 32);   // (nontemporal: measured slower)
         ptrdiff_t last = off + (KS - 1) * 32;
         asm("" : "+v"(last));
         xr[KS - 1] = *reinterpret_cast<const u32x4*>(X + (klast_ok ? last : zoff));
