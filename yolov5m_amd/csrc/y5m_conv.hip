@@ -254,6 +254,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
             if (P.epi == EPI_HEAD) {
                 float* o = reinterpret_cast<float*>(P.out);
+                const int an0 = n / P.nch, cn0 = n - an0 * P.nch;
+                if (n + 3 < P.N && cn0 + 3 < P.nch) {
+                    // the lane's 4 channels belong to one anchor: 4 consecutive floats of the permuted output
+                    // (only dword aligned, 5+nc is odd) -> one 16-byte store instead of four scalar ones
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    const f32x4u bq = *reinterpret_cast<const f32x4u*>(P.scale + n);      // (the bias is a slice of the flat parameter buffer)
+                    f32x4u w = {v[0] + bq[0], v[1] + bq[1], v[2] + bq[2], v[3] + bq[3]};
+                    *reinterpret_cast<f32x4u*>(o + ((((size_t)bi * P.naxs + an0) * P.Hg + gy) * P.Wg + gx) * P.nch + cn0) = w;
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nn = n + r;
