@@ -374,6 +374,63 @@ def g10_config0(model):
     save("g10_config0", **out)
 
 
+def g11_eval_path(model):
+    """reference YOLO_EVAL (utils/validation_utils.py) on a two-batch synthetic loader: class / obj accuracies and the
+    (preds, targets) lists handed to MeanAveragePrecision.update (captured from the stub). Dense targets come from the
+    reference's YOLO_LOSS.build_targets on a FRESH object per batch item order (anchor-decay state, App. C.1)."""
+    import tempfile
+    from utils import validation_utils as RV
+    sd = synth_state_dict()
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(11)
+    B, S = 2, 96
+    loss_obj = R.YOLO_LOSS(model, rect_training=False)
+    batches, out = [], {}
+    for bi in range(2):
+        img = torch.from_numpy(rng.integers(0, 256, (B, 3, S, S), dtype=np.uint8))
+        labs = []
+        for b in range(B):
+            n = 3
+            lab = np.zeros((n, 5))
+            lab[:, 0] = rng.integers(0, 80, n)
+            lab[:, 1:3] = rng.uniform(0.1, 0.9, (n, 2))
+            lab[:, 3:5] = rng.uniform(0.05, 0.4, (n, 2))
+            labs.append(lab)
+        model.eval()
+        with torch.no_grad():
+            o = model(img.float() / 255)
+        tg = [loss_obj.build_targets(o, lab, (S, S)) for lab in labs]
+        dense = [torch.stack([t[i] for t in tg], dim=0) for i in range(3)]
+        batches.append((img, dense))
+        out[f"b{bi}/img"] = img.numpy()
+        for i in range(3):
+            out[f"b{bi}/dense{i}"] = dense[i].numpy()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            ev = RV.YOLO_EVAL(save_logs=False, conf_threshold=0.01, nms_iou_thresh=0.6, map_iou_thresh=0.5, device="cpu",
+                              filename="g11", resume=False)
+            # the accuracies are only printed by the reference: recompute them through its own code path by
+            # enabling save_logs on the instance after construction (rounded to 3 decimals there)
+            ev.save_logs = True
+            ev.check_class_accuracy(model, [(im.clone(), [d.clone() for d in dn]) for im, dn in batches])
+            out["class_accuracy"] = np.array(ev.class_accuracy)
+            out["obj_accuracy"] = np.array(ev.obj_accuracy)
+            ev.save_logs = False
+            RV.MeanAveragePrecision.reset_mock()
+            ev.map_pr_rec(model, [(im.clone(), [d.clone() for d in dn]) for im, dn in batches], model.head.anchors, 0)
+            preds, targets = RV.MeanAveragePrecision.return_value.update.call_args[0]
+        finally:
+            os.chdir(cwd)
+    for bi in range(2):
+        out[f"b{bi}/pred_n"] = np.array(preds[bi]["boxes"].shape[0])
+        out[f"b{bi}/pred_scores"] = preds[bi]["scores"].numpy()[:64].copy()
+        out[f"b{bi}/true_boxes"] = targets[bi]["boxes"].numpy().copy()
+        out[f"b{bi}/true_labels"] = targets[bi]["labels"].numpy().copy()
+    save("g11_eval_path", **out)
+
+
 def g7_large_step(model):
     """first train-mode forward + ComputeLoss of the reference at a batch large enough that every layer width
     runs its multi-workgroup reductions (B=16 @ 320x320): the loss and its 3 components, and sampled logits"""
@@ -419,7 +476,7 @@ def g8_input_stage():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -432,3 +489,4 @@ if __name__ == "__main__":
     if "g8" in which: g8_input_stage()
     if "g9" in which: g9_nms_aladdin()
     if "g10" in which: g10_config0(model)
+    if "g11" in which: g11_eval_path(model)
