@@ -86,6 +86,28 @@ def cpu_baseline(B=4, size=640, steps=2):
                       f"({os.cpu_count()} logical CPUs)"}
 
 
+def forward_leg(model, dev, B=32, size=640, iters=10):
+    """configs[1]: forward only, batch 32 @ 640x640, bf16: eval mode (BatchNorm folded into the conv epilogues) and
+    train mode (batch statistics), images/s each (inputs resident in HBM)."""
+    from yolov5m_amd.utils.synth import synth_images
+    x = synth_images(B, size, size, seed="img/fwd").to(dev)
+    out = {}
+    for mode in ("eval", "train"):
+        model.train(mode == "train")
+        with torch.no_grad():
+            for _ in range(3):
+                model(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                model(x)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[mode] = {"images_per_sec": round(B / dt, 1), "ms": round(dt * 1e3, 3)}
+    model.train(True)
+    return {"workload": f"forward only, batch {B} @ {size}x{size}, bf16 (BASELINE.json configs[1])", "unit": "images/s", **out}
+
+
 def detect_leg(dev, B=128, size=1280, iters=5):
     """configs[4]: decode + per-image NMS on B x N candidate boxes (N = 100 800 at 1280^2), synthetic
     logits regime (ii) of SURVEY 8d: obj-logit ~ N(-5, 2^2), box/cls logits ~ N(0,1), seed 0.
@@ -236,6 +258,9 @@ def main():
         }
     if world == 1 and not args.no_detect:
         del step, images
+        model._engines = {}
+        torch.cuda.empty_cache()
+        out["forward"] = forward_leg(model, dev)
         model._engines = {}
         torch.cuda.empty_cache()
         out["detect"] = detect_leg(dev)
