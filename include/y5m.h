@@ -256,6 +256,13 @@ int y5m_bn_finalize(const float* stats, int tiles_m, int Np, int C, int64_t coun
                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* mean_out, float* invstd_out, int update_running,
                     void* ws, size_t ws_bytes, void* stream);
+/* the same for every layer of a model in ONE launch: a DEVICE table of jobs, start = running channel offset */
+typedef struct {
+    const float* gamma; const float* beta; const float* running_mean; const float* running_var;
+    float* scale; float* shift;
+    int32_t C, start;
+} y5m_fold_job;
+int y5m_bn_fold_batched(const y5m_fold_job* d_jobs, int njobs, int total_channels, float eps, void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int y5m_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                 float eps, int C, float* scale, float* shift, void* stream);

@@ -66,6 +66,12 @@ class PackJob(ctypes.Structure):
                                       "rows_p", "Kp", "cstride", "ldd", "pad_")] + [("start", c_int64)])
 
 
+class FoldJob(ctypes.Structure):
+    """mirror of y5m_fold_job (include/y5m.h)"""
+    _fields_ = ([(n, c_void_p) for n in ("gamma", "beta", "running_mean", "running_var", "scale", "shift")] +
+                [("C", c_int), ("start", c_int)])
+
+
 EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD, EPI_DGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_SILU = 0, 1
 F32, BF16 = 0, 1
@@ -113,6 +119,7 @@ _SIGS = {
     "y5m_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                 c_void_p]),
+    "y5m_bn_fold_batched": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "y5m_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "y5m_bn_act": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int,
                            c_int, c_int, c_void_p]),

@@ -418,6 +418,27 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     scale[c] = sc;
     shift[c] = beta[c] - rmean[c] * sc;
 }
+__global__ void bn_fold_batched_kernel(const y5m_fold_job* __restrict__ jobs, int njobs, int total, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const y5m_fold_job J = jobs[lo];
+    const int c = i - J.start;
+    const float sc = J.gamma[c] / sqrtf(J.running_var[c] + eps);
+    J.scale[c] = sc;
+    J.shift[c] = J.beta[c] - J.running_mean[c] * sc;
+}
+extern "C" int y5m_bn_fold_batched(const y5m_fold_job* d_jobs, int njobs, int total_channels, float eps, void* stream) {
+    if (njobs <= 0 || total_channels <= 0) return Y5M_OK;
+    hipLaunchKernelGGL(bn_fold_batched_kernel, dim3((unsigned)((total_channels + 255) / 256)), dim3(256), 0, y5m_stream(stream),
+                       d_jobs, njobs, total_channels, eps);
+    Y5M_CHECK_LAUNCH("bn_fold_batched_kernel");
+    return Y5M_OK;
+}
 extern "C" int y5m_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                            float eps, int C, float* scale, float* shift, void* stream) {
     hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, y5m_stream(stream), gamma, beta,

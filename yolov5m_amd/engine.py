@@ -215,10 +215,9 @@ class Engine:
             self.fwd.append((apply, ()))
             self._cbl_backward(lay, P)
         else:
-            def fold(lay=lay, P=P, bn=bn):
-                _lib.check(L.y5m_bn_fold(_lib.ptr(P["g"]), _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
-                                         BN_EPS, lay.cout, bn[0].data_ptr(), bn[1].data_ptr(), st()), "y5m_bn_fold")
-            self.pack.append((fold, ()))
+            # eval mode: BatchNorm folded into (scale, shift); all layers in ONE launch (see _batch_packs)
+            self._fold_jobs.append((P["g"].data_ptr(), P["b"].data_ptr(), P["rm"].data_ptr(), P["rv"].data_ptr(),
+                                    bn[0].data_ptr(), bn[1].data_ptr(), lay.cout))
             a = self._conv_args(x, lay.wf, dest.ptr, Ho, Wo, kk, ss, pp, cout, dest.ld, EPI_AFFINE_ACT, Kp,
                                 act=ACT_SILU, scale=bn[0].data_ptr(), shift=bn[1].data_ptr(),
                                 res=res.ptr if res is not None else None, ldres=res.ld if res is not None else 0)
@@ -702,6 +701,7 @@ class Engine:
         L, dt = self.L, self.dtype
         B, H, W = self.B, self.H, self.W
         self.pack, self.heads, self._stat_users = [], [], []
+        self._fold_jobs = []
         self._gw_floats = 0
         self._grad_done = []
         first_out = self.model.first_out
@@ -834,6 +834,21 @@ class Engine:
                        "y5m_pack_weights_batched")
         pack_all.kind = "pack_weights"
         self.pack = [(pack_all, ())] + rest
+        if self._fold_jobs:
+            fj, start = [], 0
+            for (g_, b_, rm, rv, sc, sh, C) in self._fold_jobs:
+                j = _lib.FoldJob()
+                j.gamma, j.beta, j.running_mean, j.running_var, j.scale, j.shift, j.C, j.start = g_, b_, rm, rv, sc, sh, C, start
+                start += C
+                fj.append(j)
+            raw = bytes((_lib.FoldJob * len(fj))(*fj))
+            self._fold_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            nf, totc = len(fj), start
+
+            def fold_all():
+                _lib.check(L.y5m_bn_fold_batched(_lib.ptr(self._fold_table), nf, totc, BN_EPS, _lib.stream_ptr()),
+                           "y5m_bn_fold_batched")
+            self.pack.append((fold_all, ()))
 
     # ------------------------------------------------------------------ execution
     @staticmethod
