@@ -1054,11 +1054,22 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]);   // total L2 norm
 }
+__device__ __forceinline__ void adam_one(float& pw, float g, float& mi, float& vi, float clip, float lr_bc1, float b1, float b2,
+                                         float eps, float wd, float bc2_sqrt) {
+    float gi = g * clip;
+    gi = gi + wd * pw;                            // Adam(weight_decay=): L2 added to the gradient
+    mi = b1 * mi + (1.0f - b1) * gi;
+    vi = b2 * vi + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pw = pw - lr_bc1 * (mi / denom);
+}
+// 4 parameters per thread (16-byte accesses on all 7 streams); the tail is handled by the last threads one by one
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int64_t n, const float* __restrict__ gnorm, float max_norm, float lr, float b1, float b2,
                             float eps, float wd, const int32_t* __restrict__ d_step) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n4 = n >> 2;
+    if (i4 > n4) return;
     // the step counter lives on the device so a captured hipGraph replays with the right bias correction
     const float stepf = (float)d_step[0];
     const float bc1 = 1.0f - powf(b1, stepf);
@@ -1068,14 +1079,22 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         clip = max_norm / (gnorm[0] + 1e-6f);
         clip = clip > 1.0f ? 1.0f : clip;
     }
-    const float pw = p[i];
-    float gi = g[i] * clip;
-    gi = gi + wd * pw;                            // Adam(weight_decay=): L2 added to the gradient
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pw - (lr / bc1) * (mi / denom);
+    const float lr_bc1 = lr / bc1;
+    if (i4 < n4) {
+        float4 pw = reinterpret_cast<float4*>(p)[i4], mi = reinterpret_cast<float4*>(m)[i4], vi = reinterpret_cast<float4*>(v)[i4];
+        const float4 gq = reinterpret_cast<const float4*>(g)[i4];
+        adam_one(pw.x, gq.x, mi.x, vi.x, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+        adam_one(pw.y, gq.y, mi.y, vi.y, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+        adam_one(pw.z, gq.z, mi.z, vi.z, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+        adam_one(pw.w, gq.w, mi.w, vi.w, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[i4] = pw; reinterpret_cast<float4*>(m)[i4] = mi; reinterpret_cast<float4*>(v)[i4] = vi;
+    } else {
+        for (int64_t i = n4 << 2; i < n; ++i) {
+            float pw = p[i], mi = m[i], vi = v[i];
+            adam_one(pw, g[i], mi, vi, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+            p[i] = pw; m[i] = mi; v[i] = vi;
+        }
+    }
 }
 extern "C" size_t y5m_adam_workspace_bytes(void) { return (SQ_BLOCKS + 64) * sizeof(float); }
 extern "C" int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, void* stream) {
@@ -1092,7 +1111,9 @@ extern "C" int y5m_adam_step(float* p, const float* g, float* m, float* v, int64
                              float lr, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_step,
                              void* stream) {
     Y5M_REQUIRE(d_step != nullptr, "d_step (device int32, >= 1) is required");
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), p, g, m, v, n, gnorm, max_norm, lr,
+    Y5M_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0,
+                "adam buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((n >> 2) + 1)), dim3(EW_T), 0, y5m_stream(stream), p, g, m, v, n, gnorm, max_norm, lr,
                        beta1, beta2, eps, weight_decay, d_step);
     Y5M_CHECK_LAUNCH("adam_kernel");
     return Y5M_OK;
