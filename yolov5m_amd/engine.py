@@ -114,7 +114,9 @@ class Engine:
         # pointwise weight gradients without atomics: one partial slice per pixel range, summed by the unpack in a
         # fixed order (bit-reproducible). OFF by default: measured 32.6 vs 31.2 ms/step -- the slice traffic (N x C x 4
         # bytes per pixel range, up to 2.4 MB for the 768-channel layers) costs more than the L2 atomics it replaces.
-        self.wgrad_slices = os.environ.get("Y5M_WGRAD_SLICES", "0") != "0"          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
+        self.wgrad_slices = os.environ.get("Y5M_WGRAD_SLICES", "0") != "0"
+        self.wgrad_direct = os.environ.get("Y5M_WGRAD_DIRECT", "1") != "0"    # 1x1 layers: atomics straight into flat_grads
+        self._direct_wgrads = 0          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
         self._bwd_stack = []
         self.layers = []
         self._scratch_elems = 0
@@ -420,6 +422,13 @@ class Engine:
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
         fs = [lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad")]
         use_slices = self.wgrad_slices and wa.th == 1 and wa.tw == 1
+        if (self.wgrad_direct and not use_slices and wa.th == 1 and wa.tw == 1 and len(unpacks) == 1 and unpacks[0][0] == 0
+                and unpacks[0][1] == wa.N and unpacks[0][2] == wa.lddw and unpacks[0][4] == 0):
+            # a 1x1 layer's packed gradient [Cout][Cin] IS the reference layout [Cout][Cin][1][1]: accumulate straight
+            # into the flat gradient buffer (zeroed at the start of the backward list), no unpack launch
+            wa.dwgt = unpacks[0][5]
+            self._direct_wgrads += 1
+            return fs
         if use_slices:
             wa.slices_cap = 4096
             ns = L.y5m_wgrad_slices(ctypes.byref(wa), dt)
@@ -755,6 +764,7 @@ class Engine:
             self.gw = torch.zeros((self._gw_floats,), dtype=torch.float32, device=self.dev)
             # expand the backward stack in reverse order; plan-time gradient-written flags
             self.bwd.append((lambda: self.gw.zero_(), ()))
+            self.bwd.append((lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, ()))
             # bwd_marks[i] = (op index after which unit i's parameter gradients are final, unit name,
             # device address of its weight gradient inside the flat buffer) -- in backward order
             self.bwd_marks = []
