@@ -331,3 +331,32 @@ def test_eval_path_matches_reference_yolo_eval(golden):
         np.testing.assert_array_equal(targets[bi]["labels"].cpu().numpy(), g[f"b{bi}/true_labels"])
         np.testing.assert_allclose(targets[bi]["boxes"].cpu().numpy(), g[f"b{bi}/true_boxes"], rtol=1e-5, atol=1e-4)
     assert m.training                                    # the reference leaves the model in train mode (:83, :144)
+
+
+def test_train_loop_mirror_runs_both_input_paths():
+    """train_loop (reference utils/training_utils.py:81-132): same control flow -- accumulation to the nominal batch 64
+    (batch 2 -> one optimizer step per 32 batches, plus the forced step on the epoch's last batch), clip, optimizer --
+    with the float host path of the reference AND the uint8 device input stage; same parameters after an epoch of
+    identical batches (multi_scale off so both paths see identical images)"""
+    import torch
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import train_loop
+    g = torch.Generator().manual_seed(4)
+    batches = []
+    for i in range(3):
+        img = torch.randint(0, 256, (2, 3, 96, 96), generator=g, dtype=torch.uint8)
+        lab = synth_labels(2, 4, seed=f"tl{i}")
+        batches.append((img, lab))
+    results = []
+    for as_float in (True, False):
+        m = _model("f32"); m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY)
+        loader = [((im.float() if as_float else im), lb) for im, lb in batches]     # the reference loader yields 0..255 values
+        mean_loss = train_loop(m, loader, opt, ComputeLoss(m), scaler=None, epoch=0, num_epochs=1, multi_scale_training=False)
+        assert np.isfinite(mean_loss)
+        results.append((mean_loss, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()))
+    assert abs(results[0][0] - results[1][0]) <= 1e-5 * abs(results[0][0])
+    p0 = torch.cat([p.detach().reshape(-1) for p in _model("f32").parameters()]).cpu()
+    d0, d1 = results[0][1] - p0, results[1][1] - p0
+    assert float(d0.abs().max()) > 0                       # the epoch's last batch forced one optimizer step (:116)
+    assert float((d0 - d1).abs().max()) <= 1e-3 * float(d0.abs().max())
