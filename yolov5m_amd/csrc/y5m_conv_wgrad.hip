@@ -273,7 +273,40 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
             }
         }
     }
-    if (ch_lo < ch_hi || slices) {
+    // K-waves (WK > 1: the waves of a block that split the pixels of every chunk) first add their partial tiles in
+    // LDS, so the block issues ONE set of atomics instead of WK (pointwise layers are bound by those atomics)
+    bool writer = true;
+    if constexpr (WK > 1) {
+        if (!slices) {
+            constexpr int TILE_F = NFR * CFR * 4 * 64;             // floats of one wave's accumulators
+            float* red = reinterpret_cast<float*>(smem);          // [(WK-1)][WN*WC][TILE_F]
+            __syncthreads();                                       // every wave is done with the staged tiles
+            if (wk > 0) {
+                float* dstp = red + ((size_t)(wk - 1) * (WN * WC) + (wid % (WN * WC))) * TILE_F + lane;
+#pragma unroll
+                for (int a = 0; a < NFR; ++a)
+#pragma unroll
+                    for (int b = 0; b < CFR; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dstp[((a * CFR + b) * 4 + r) * 64] = acc[a][b][r];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int k = 1; k < WK; ++k) {
+                    const float* srcp = red + ((size_t)(k - 1) * (WN * WC) + (wid % (WN * WC))) * TILE_F + lane;
+#pragma unroll
+                    for (int a = 0; a < NFR; ++a)
+#pragma unroll
+                        for (int b = 0; b < CFR; ++b)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[a][b][r] += srcp[((a * CFR + b) * 4 + r) * 64];
+                }
+            }
+            writer = wk == 0;
+        }
+    }
+    if ((ch_lo < ch_hi || slices) && writer) {
         // D[n][c]: lane owns n = (lane>>4)*4 + r, c = lane&15 -> atomics coalesced along c
         const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -350,13 +383,16 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     static int sb = -1;                                   // single LDS buffer (default; Y5M_WGRAD_SB=0: double buffer): in the full step -0.15 ms
     if (sb < 0) { const char* e = getenv("Y5M_WGRAD_SB"); sb = e ? atoi(e) : 1; }
     const bool use_sb = sb && TPB == 1;
-    const size_t lds = (use_sb ? 1 : 2) * (size_t)(C::YB + C::XB);
+    const size_t red_bytes = WK > 1 ? (size_t)(WK - 1) * WN * WC * NFR * CFR * 4 * 64 * sizeof(float) : 0;
+    const size_t tile_bytes = (use_sb ? 1 : 2) * (size_t)(C::YB + C::XB);
+    const size_t lds = tile_bytes > red_bytes ? tile_bytes : red_bytes;
     const unsigned grid = (unsigned)(P.tiles_n * P.tiles_c * taps * P.ksplit);
     auto kern = use_sb ? wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true> : wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::YB + C::XB));
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (C::YB + C::XB)));
+        const int cap = (int)(2 * (size_t)(C::YB + C::XB) > red_bytes ? 2 * (size_t)(C::YB + C::XB) : red_bytes);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
@@ -377,6 +413,9 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     if (n48 && c48) return launch_wgrad<T, 1, 1, 4, 3>(P, st);     // 48 x 48
     if (n48) return launch_wgrad<T, 1, 2, 2, 3>(P, st);            // 48 x 96
     if (c48) return launch_wgrad<T, 2, 1, 2, 3>(P, st);            // 96 x 48
+    static int pw8 = -1;                                           // Y5M_WGRAD_PW8: 8-wave 96 x 96 tile (2 K-waves) for pointwise layers
+    if (pw8 < 0) { const char* e = getenv("Y5M_WGRAD_PW8"); pw8 = e ? atoi(e) : 0; }
+    if (pw8 && taps == 1) return launch_wgrad<T, 2, 2, 2, 3>(P, st);
     // wide layers: 192 x 96 block (wave 96 x 48: 9 transposing reads per 18 MFMAs instead of 12 per 9, and
     // 1.33x fewer staged bytes per MFMA); Y5M_WGRAD_BIG=2: 192 x 192 (wave 96 x 96, one block per CU), 0: off
     static int big = -1;
