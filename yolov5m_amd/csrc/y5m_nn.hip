@@ -453,14 +453,14 @@ extern "C" int y5m_bn_fold(const float* gamma, const float* beta, const float* r
 // re-loaded per pixel before: 6 parameter vectors per 2 data vectors) and has U independent rows in flight.
 struct EwGeom { int CG, groups, RP; unsigned gx; };
 static int g_ew_gx = -1;
-static inline EwGeom ew_geom(int64_t M, int C8, int max_gx) {
+static inline EwGeom ew_geom(int64_t M, int C8, int max_gx, int threads = 256) {
     if (g_ew_gx < 0) { const char* e = getenv("Y5M_EW_GX"); g_ew_gx = e ? atoi(e) : 0; }
     if (g_ew_gx > 0 && max_gx > 512) max_gx = g_ew_gx;
     EwGeom g;
     g.CG = 1;
     for (int d = C8 < 32 ? C8 : 32; d >= 1; --d) if (C8 % d == 0) { g.CG = d; break; }
     g.groups = C8 / g.CG;
-    g.RP = 256 / g.CG;
+    g.RP = threads / g.CG;
     int64_t gx = (M + g.RP - 1) / g.RP;
     const int64_t cap = max_gx / g.groups > 0 ? max_gx / g.groups : 1;
     g.gx = (unsigned)(gx < 1 ? 1 : (gx > cap ? cap : gx));
@@ -534,12 +534,15 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
 // dgamma/dbeta and the apply coefficients cB/cD, (3) apply.
 // =================================================================================================
 
+#ifndef BNR_THREADS
+#define BNR_THREADS 256
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
+__global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                            int ldy, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int64_t M, int C, int CG, int RP,
                                                            int act, float* __restrict__ part) {
-    __shared__ float sm[2][256][9];            // [which][thread][k] (+1: the 8-float rows land on distinct banks)
+    __shared__ float sm[2][BNR_THREADS][9];    // [which][thread][k] (+1: the 8-float rows land on distinct banks)
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
     const bool active = rl < RP;
     const int c = (blockIdx.y * CG + cl) * 8;
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     __syncthreads();
     // block partial: NCH = CG*8 channels x 2 sums, summed over the RP row lanes in a fixed order
     const int NCH = CG * 8;
-    for (int t = threadIdx.x; t < 2 * NCH; t += 256) {
+    for (int t = threadIdx.x; t < 2 * NCH; t += BNR_THREADS) {
         const int which = t / NCH, ch = t - which * NCH;
         float acc = 0.f;
         for (int r = 0; r < RP; ++r) acc += sm[which][r * CG + (ch >> 3)][ch & 7];
@@ -661,8 +664,8 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     w += y5m_align((size_t)2 * C * 4);
     float* stage = reinterpret_cast<float*>(w);
     hipStream_t st = y5m_stream(stream);
-    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX);            // (swept 256..2048 in the full step: 512 is best)
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(256), 0, st,
+    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);   // (swept 256..2048 in the full step: 512 is best)
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st,
                                          (const T*)dz, lddz, (const T*)y, ldy, scale, shift, M, C, gr.CG, gr.RP, act, part);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     BnFinArgs F{};
