@@ -56,6 +56,40 @@ def test_decode_vs_oracle_640(anchors):
     np.testing.assert_allclose(out[..., 1:], ref[..., 1:], rtol=1e-4, atol=1e-5)
 
 
+def test_decode_sigmoid_ties_and_ragged_tail(anchors):
+    """Class logits that saturate sigmoid in fp32 (several classes at exactly 1.0 or 0.0): the first
+    maximum in SIGMOID space must win, as torch.argmax does (plot_utils.py:27). B=1 leaves a ragged last
+    tile on every scale (19200, 4800, 1200 cells are not all multiples of 64), served by the generic kernel."""
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    shapes = [(80, 80), (40, 40), (20, 20)]
+    p = [uniform(f"dectie/{i}", (1, 3, ny, nx, 85), -4.0, 4.0) for i, (ny, nx) in enumerate(shapes)]
+    rng = np.random.default_rng(7)
+    for t in p:
+        flat = t.view(-1, 85)
+        n = flat.shape[0]
+        rows = torch.from_numpy(rng.permutation(n)[: n // 2])
+        for k, r in enumerate(rows.tolist()):
+            cls = np.sort(rng.permutation(80)[:3]) + 5
+            if k % 3 == 0:      # three saturated classes, the LAST holds the largest logit
+                flat[r, cls] = torch.tensor([20.0, 30.0, 40.0])
+            elif k % 3 == 1:    # every class saturates to 0.0
+                flat[r, 5:] = -120.0 - torch.arange(80, dtype=torch.float32).flip(0)
+            else:               # exact duplicates of the maximum logit
+                flat[r, cls] = 9.5
+    ref = loss_ref.cells_to_bboxes(p, anchors, [8, 16, 32], is_pred=True).numpy()
+    out = cells_to_bboxes([t.to(DEV) for t in p], anchors.to(DEV), [8, 16, 32], is_pred=True, to_list=False)
+    out = out.cpu().numpy()
+    # saturated / duplicated rows have ties only by construction: they must match exactly
+    sig = 1.0 / (1.0 + np.exp(-np.concatenate([t.view(-1, 85)[:, 5:].numpy() for t in p]).astype(np.float64)))
+    top2 = np.sort(sig, axis=1)[:, -2:]
+    tie_rows = (top2[:, 1] - top2[:, 0]) < 1e-6
+    constructed = np.concatenate([(t.view(-1, 85)[:, 5:].abs().max(1).values > 9.0).numpy() for t in p])
+    assert constructed.sum() > 1000
+    assert np.array_equal(out[0, constructed, 0], ref[0, constructed, 0])
+    assert np.array_equal(out[0, ~tie_rows, 0], ref[0, ~tie_rows, 0])
+    np.testing.assert_allclose(out[..., 1:], ref[..., 1:], rtol=1e-4, atol=1e-5)
+
+
 # ---------------------------------------------------------------------------------------------- NMS
 def _check_nms(bx, thr, iou, max_det=300):
     from yolov5m_amd.utils.bboxes_utils import nms_batched, non_max_suppression

@@ -14,53 +14,18 @@
 // One wave decodes 64 consecutive cells. The 64*(5+nc) logits of those cells are one contiguous
 // run in HBM: they are read with coalesced 16-byte loads into an LDS tile with an odd row stride,
 // then lane i walks the channels of cell i conflict-free.
-// Specialisation for a compile-time channel count (85 = 5 + 80 classes): a full 64-cell tile is
-// exactly NV = 64*NCH/4 float4 per wave; ALL of them are issued before the first LDS write (memory-level
-// parallelism), and every (cell, channel) position is a compile-time function of (iteration, lane).
+//
+// Specialisation for a compile-time channel count (85 = 5 + 80 classes), full tiles only. A tile is
+// exactly NV = 64*NCH/4 float4; NCH is odd, so the conflict-free row stride equals NCH and the LDS image
+// of a tile IS the global byte stream (16-byte linear LDS writes, no (cell, channel) arithmetic).
+// The grid is persistent: a one-wave block walks tiles blockIdx.x, +gridDim.x, ... and issues ALL loads of
+// its next tile before it starts the per-cell phase of the current one, so the memory pipe stays busy
+// during the LDS/ALU phase (measured: the load stream alone runs at 5.4 TB/s, the un-pipelined kernel at 3.0).
 template <int NCH>
-__global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel_c(
-    const float* __restrict__ logits, int64_t cells, int naxs, int ny, int nx,
-    float aw0, float ah0, float aw1, float ah1, float aw2, float ah2, float stride,
-    float* __restrict__ out, int64_t N_total, int64_t row_offset) {
-    constexpr int LS = NCH | 1;
-    constexpr int NV = 64 * NCH / 4;            // float4 per full tile
-    constexpr int IT = (NV + 63) / 64;
-    __shared__ float tile[64 * LS];
-    const int lane = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * 64;
-    const int ncell = (int)((cells - c0) < 64 ? (cells - c0) : 64);
-    const float* src = logits + c0 * NCH;
-    if (ncell == 64) {
-        float4 q[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int v = lane + 64 * it;
-            q[it] = v < NV ? reinterpret_cast<const float4*>(src)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int v = lane + 64 * it;
-            if (v < NV) {
-                const int e = 4 * v;
-                int cell = e / NCH, ch = e - cell * NCH;
-                const float vals[4] = {q[it].x, q[it].y, q[it].z, q[it].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    tile[cell * LS + ch] = vals[k];
-                    if (++ch == NCH) { ch = 0; ++cell; }
-                }
-            }
-        }
-    } else {
-        for (int e = lane; e < ncell * NCH; e += 64) {
-            const int cell = e / NCH, ch = e - cell * NCH;
-            tile[cell * LS + ch] = src[e];
-        }
-    }
-    __syncthreads();
-    if (lane >= ncell) return;
-    const float* row = tile + lane * LS;
-    const int64_t cell = c0 + lane;
+__device__ __forceinline__ void decode_cell_c(const float* __restrict__ row, int64_t cell, int naxs, int ny, int nx,
+                                              float aw0, float ah0, float aw1, float ah1, float aw2, float ah2,
+                                              float stride, float* __restrict__ out, int64_t N_total,
+                                              int64_t row_offset) {
     const int gx = (int)(cell % nx);
     int64_t t = cell / nx;
     const int gy = (int)(t % ny);
@@ -77,14 +42,26 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel_c(
     const float tw = 2.0f * sw, th = 2.0f * sh;
     const float w = (tw * tw) * (aw * stride);
     const float h = (th * th) * (ah * stride);
+    // argmax over SIGMOID values, first max wins (plot_utils.py:27). Branch-free walk over the LOGITS: `best` is
+    // the first index of the largest logit, `prev` the largest logit before it. sigmoid is monotone, so an
+    // earlier class can only tie in sigmoid space if sigmoid(prev) == sigmoid(best): only then replay the
+    // reference's walk over sigmoid values.
     int best = 0;
-    float best_logit = row[5], best_sig = sigmoidf_(row[5]);
-#pragma unroll 4
+    float best_logit = row[5], prev = -INFINITY;
+#pragma unroll
     for (int c = 1; c < NCH - 5; ++c) {
         const float l = row[5 + c];
-        if (l > best_logit) {
-            const float s = sigmoidf_(l);
-            if (s > best_sig) { best_sig = s; best = c; best_logit = l; }
+        const bool up = l > best_logit;
+        prev = up ? best_logit : prev;
+        best = up ? c : best;
+        best_logit = up ? l : best_logit;
+    }
+    if (sigmoidf_(prev) == sigmoidf_(best_logit)) {
+        best = 0;
+        float bs = sigmoidf_(row[5]);
+        for (int c = 1; c < NCH - 5; ++c) {
+            const float sc = sigmoidf_(row[5 + c]);
+            if (sc > bs) { bs = sc; best = c; }
         }
     }
     float* o = out + (b * N_total + row_offset + ((int64_t)a * ny + gy) * nx + gx) * 6;
@@ -93,15 +70,58 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel_c(
     reinterpret_cast<float2*>(o)[2] = make_float2(w, h);
 }
 
+template <int NCH>
+__global__ __launch_bounds__(64) void decode_pred_kernel_c(
+    const float* __restrict__ logits, int64_t tiles, int naxs, int ny, int nx,
+    float aw0, float ah0, float aw1, float ah1, float aw2, float ah2, float stride,
+    float* __restrict__ out, int64_t N_total, int64_t row_offset) {
+    static_assert((NCH & 1) == 1, "specialisation assumes an odd channel count");
+    constexpr int NV = 64 * NCH / 4;            // float4 per tile
+    constexpr int IT = (NV + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float tile[64 * NCH];
+    const int lane = threadIdx.x;
+    float4 q[IT];
+    int64_t t = blockIdx.x;
+    {
+        const float4* src = reinterpret_cast<const float4*>(logits + t * 64 * NCH);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = lane + 64 * it;
+            q[it] = v < NV ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (; t < tiles; t += gridDim.x) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = lane + 64 * it;
+            if (v < NV) reinterpret_cast<float4*>(tile)[v] = q[it];
+        }
+        __syncthreads();
+        const int64_t tn = t + gridDim.x;
+        if (tn < tiles) {
+            const float4* src = reinterpret_cast<const float4*>(logits + tn * 64 * NCH);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int v = lane + 64 * it;
+                q[it] = v < NV ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        decode_cell_c<NCH>(tile + lane * NCH, t * 64 + lane, naxs, ny, nx, aw0, ah0, aw1, ah1, aw2, ah2, stride, out,
+                           N_total, row_offset);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(DEC_THREADS) void decode_pred_kernel(
-    const float* __restrict__ logits, int64_t cells, int naxs, int ny, int nx, int nch,
+    const float* __restrict__ logits, int64_t cell_base, int64_t cells, int naxs, int ny, int nx, int nch,
     float aw0, float ah0, float aw1, float ah1, float aw2, float ah2, float stride,
     float* __restrict__ out, int64_t N_total, int64_t row_offset) {
     extern __shared__ __attribute__((aligned(16))) float dec_lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int lstride = nch | 1;
     float* tile = dec_lds + (size_t)wid * 64 * lstride;
-    const int64_t c0 = ((int64_t)blockIdx.x * DEC_WAVES + wid) * 64;
+    const int64_t c0 = cell_base + ((int64_t)blockIdx.x * DEC_WAVES + wid) * 64;   // cells [cell_base, cells)
     if (c0 >= cells) return;
     const int ncell = (int)((cells - c0) < 64 ? (cells - c0) : 64);
     const int nelem = ncell * nch;
@@ -189,17 +209,28 @@ extern "C" int y5m_decode_scale(const float* logits, int B, int naxs, int ny, in
         hipFuncSetAttribute((const void*)decode_pred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int64_t blocks = (cells + DEC_THREADS - 1) / DEC_THREADS;
     const float* a = anchors_scale_host;
-    if (nch == 85 && (((uintptr_t)logits) & 15) == 0) {
-        hipLaunchKernelGGL(decode_pred_kernel_c<85>, dim3((unsigned)((cells + 63) / 64)), dim3(DEC_THREADS), 0,
-                           y5m_stream(stream), logits, cells, naxs, ny, nx, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
+    int64_t cell_base = 0;
+    if (nch == 85 && (((uintptr_t)logits) & 15) == 0 && cells >= 64) {
+        // full tiles on the pipelined kernel (persistent grid: 7 one-wave blocks fit a CU's LDS); a ragged last
+        // tile falls through to the generic kernel
+        const int64_t tiles = cells / 64;
+        static int grid_cap = 0;
+        if (!grid_cap) {
+            const char* e = getenv("Y5M_DECODE_GRID");
+            grid_cap = e ? atoi(e) : 7 * 256;
+            if (grid_cap < 1) grid_cap = 1;
+        }
+        hipLaunchKernelGGL(decode_pred_kernel_c<85>, dim3((unsigned)(tiles < grid_cap ? tiles : grid_cap)), dim3(64), 0,
+                           y5m_stream(stream), logits, tiles, naxs, ny, nx, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
                            N_total, row_offset);
         Y5M_CHECK_LAUNCH("decode_pred_kernel_c<85>");
-        return Y5M_OK;
+        cell_base = tiles * 64;
+        if (cell_base == cells) return Y5M_OK;
     }
+    const int64_t blocks = (cells - cell_base + DEC_THREADS - 1) / DEC_THREADS;
     hipLaunchKernelGGL(decode_pred_kernel, dim3((unsigned)blocks), dim3(DEC_THREADS), lds, y5m_stream(stream),
-                       logits, cells, naxs, ny, nx, nch, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
+                       logits, cell_base, cells, naxs, ny, nx, nch, a[0], a[1], a[2], a[3], a[4], a[5], stride, out,
                        N_total, row_offset);
     Y5M_CHECK_LAUNCH("decode_pred_kernel");
     return Y5M_OK;
