@@ -27,5 +27,9 @@ for (M, C) in ((1638400, 48), (1638400, 96), (409600, 96), (409600, 192), (10240
     t_act = timeit(lambda: L.y5m_bn_act(_lib.ptr(y), C, _lib.ptr(sc), _lib.ptr(sh), None, 0, _lib.ptr(out), C, M, C, ACT_SILU, BF16, st))
     t_bwd = timeit(lambda: L.y5m_bn_bwd(_lib.ptr(dz), C, _lib.ptr(y), C, _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(mu), _lib.ptr(inv), M, C, ACT_SILU,
                                         _lib.ptr(dg), _lib.ptr(db), 0, _lib.ptr(out), C, _lib.ptr(ws), wsb, BF16, st))
+    part = torch.zeros(512 * 2 * C, device=dev)
+    t_app = timeit(lambda: L.y5m_bn_bwd_from_partials(_lib.ptr(part), 512, C, _lib.ptr(dz), C, _lib.ptr(y), C, _lib.ptr(sc), _lib.ptr(sh),
+                                                      _lib.ptr(mu), _lib.ptr(inv), M, C, ACT_SILU, _lib.ptr(dg), _lib.ptr(db), 0,
+                                                      _lib.ptr(out), C, _lib.ptr(ws), wsb, BF16, st))
     b = M * C * 2
-    print(f"M={M:8d} C={C:4d} ({b/1e6:6.1f} MB/tensor): copy {2*b/t_copy/1e12:5.2f} TB/s ({t_copy*1e6:6.1f} us) | bn_act {2*b/t_act/1e12:5.2f} TB/s ({t_act*1e6:6.1f} us) | bn_bwd(10B/elem) {5*b/t_bwd/1e12:5.2f} TB/s ({t_bwd*1e6:6.1f} us)")
+    print(f"M={M:8d} C={C:4d} ({b/1e6:6.1f} MB/tensor): copy {2*b/t_copy/1e12:5.2f} TB/s ({t_copy*1e6:6.1f} us) | bn_act {2*b/t_act/1e12:5.2f} TB/s ({t_act*1e6:6.1f} us) | bn_bwd(10B/elem) {5*b/t_bwd/1e12:5.2f} TB/s ({t_bwd*1e6:6.1f} us) | reduce alone {2*b/(t_bwd-t_app)/1e12:5.2f} TB/s ({(t_bwd-t_app)*1e6:6.1f} us)")
