@@ -9,11 +9,15 @@ for. Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, point-to-point, no switch
     multiplied by its local batch size, ultralytics_loss.py:120), i.e. exactly the gradient of the
     single-process loss on the concatenated batch up to BatchNorm's per-replica statistics (the
     reference has no SyncBN to match);
-  * buckets are contiguous ranges of the flat buffer taken in BACKWARD order (head first, stem last);
-    bucket k is all-reduced on the communication stream as soon as the backward segment that finalises
-    it has been enqueued, while the next segment's dgrad/wgrad kernels keep running;
+  * NativeTrainStep runs forward+loss+backward as ONE captured hipGraph, then the all-reduce of the whole flat
+    buffer (GradAllReduce.__call__, stream-ordered), then the optimizer graph: at 84.8 MB the exchange is
+    well under a millisecond of a ~31 ms step, so it is not split. `make_buckets` / `launch` / `wait` are the
+    pieces of the bucketed variant (contiguous ranges in BACKWARD order, head first, cut at layer units) for an
+    eager backward that wants to overlap them; they are covered by the gloo tests;
   * the optimizer then runs identically on every rank (no parameter broadcast after step 0).
-Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests).
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests). `Y5M_DIST_BACKEND=gloo`
+forces gloo on GPU tensors too: with LOCAL_RANK folded onto the visible devices this lets a 1-GPU box run the
+whole multi-process flow (RCCL itself refuses two ranks on one device).
 """
 import torch
 import torch.distributed as dist
@@ -28,8 +32,10 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        backend = backend or os.environ.get("Y5M_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            if backend != "nccl":
+                local %= torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
