@@ -279,6 +279,9 @@ struct NmsLds {
     unsigned long long keys[NMS_CAP];
     float kbox[NMS_MAXK * 4];
     float karea[NMS_MAXK];
+    int kidx[NMS_MAXK];           // source row of every kept box (rows are written out at the end)
+    unsigned long long colmask[64];   // colmask[i]: lanes j > i of the current 64-candidate tile that candidate i suppresses
+    unsigned long long deadm[NMS_T / 64];   // per wave: tile lanes suppressed by boxes kept earlier in this group
     float sbox[NMS_T * 4];
     float sarea[NMS_T];
     int sidx[NMS_T];
@@ -526,52 +529,71 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
                 L.sidx[pos] = src;
             }
             __syncthreads();
-            if (wid == 0) {
-                volatile float* kbox = L.kbox;
-                volatile float* karea = L.karea;
-                int nk = nk0;
-                for (int sb = 0; sb < ns && nk < max_det; sb += 64) {
-                    const int j = sb + lane;
-                    bool al = j < ns;
-                    NmsBox mb = {0.f, 0.f, 0.f, 0.f, 0.f};
-                    int msrc = 0;
-                    if (al) {
-                        mb.x1 = L.sbox[4 * j]; mb.y1 = L.sbox[4 * j + 1];
-                        mb.x2 = L.sbox[4 * j + 2]; mb.y2 = L.sbox[4 * j + 3];
-                        mb.area = L.sarea[j];
-                        msrc = L.sidx[j];
-                    }
-                    // boxes kept earlier in THIS group (after the block-wide test above)
-                    for (int k = nk0; k < nk && al; ++k) {
-                        if (nms_suppresses<MODE>(kbox[4 * k], kbox[4 * k + 1], kbox[4 * k + 2], kbox[4 * k + 3],
-                                           karea[k], mb, iou_thr))
-                            al = false;
-                    }
-                    unsigned long long mask = __ballot(al);
-                    while (mask != 0ull && nk < max_det) {
-                        const int i = __ffsll((long long)mask) - 1;
-                        const float ix1 = __shfl(mb.x1, i, 64), iy1 = __shfl(mb.y1, i, 64);
-                        const float ix2 = __shfl(mb.x2, i, 64), iy2 = __shfl(mb.y2, i, 64);
-                        const float ia = __shfl(mb.area, i, 64);
-                        if (lane == i) {
-                            kbox[4 * nk] = ix1; kbox[4 * nk + 1] = iy1;
-                            kbox[4 * nk + 2] = ix2; kbox[4 * nk + 3] = iy2;
-                            karea[nk] = ia;
-                            float cls, sc, x1, y1, x2, y2;
-                            NmsBox tmp;
-                            nms_load<MODE>(bx + (int64_t)msrc * 6, cls, sc, x1, y1, x2, y2, tmp);
-                            float* o = orow + (int64_t)nk * 6;
-                            o[0] = cls; o[1] = sc; o[2] = x1; o[3] = y1; o[4] = x2; o[5] = y2;
-                            oidx[nk] = msrc;
-                            al = false;
-                        }
-                        ++nk;
-                        if (al && lane > i && nms_suppresses<MODE>(ix1, iy1, ix2, iy2, ia, mb, iou_thr)) al = false;
-                        mask = __ballot(al);
-                    }
+            // ---- resolve the survivors in tiles of 64 (sorted order = lane order), all 16 waves per tile:
+            //   (1) wave w tests the tile against the boxes kept earlier in THIS group, k = nk0+w, nk0+w+16, ...
+            //   (2) wave w tests tile candidates i = 4w..4w+3 against every later lane j  -> colmask[i]
+            //   (3) wave 0 walks the tile on the scalar unit: first alive lane is kept, alive &= ~colmask[kept];
+            //       nothing on that chain touches memory (64-bit masks in SGPRs, v_readlane of the column masks)
+            int nk = nk0;
+            for (int sb = 0; sb < ns && nk < max_det; sb += 64) {
+                const int j = sb + lane;
+                const bool jv = j < ns;
+                NmsBox mb = {0.f, 0.f, 0.f, 0.f, 0.f};
+                int msrc = 0;
+                if (jv) {
+                    mb.x1 = L.sbox[4 * j]; mb.y1 = L.sbox[4 * j + 1];
+                    mb.x2 = L.sbox[4 * j + 2]; mb.y2 = L.sbox[4 * j + 3];
+                    mb.area = L.sarea[j];
+                    msrc = L.sidx[j];
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) L.s_nk = nk;
+                bool dead = false;
+                for (int k = nk0 + wid; k < nk; k += NMS_T / 64)
+                    dead |= nms_suppresses<MODE>(L.kbox[4 * k], L.kbox[4 * k + 1], L.kbox[4 * k + 2], L.kbox[4 * k + 3],
+                                                 L.karea[k], mb, iou_thr);
+                const unsigned long long dm = __ballot(dead && jv);
+                if (lane == 0) L.deadm[wid] = dm;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * wid + q;
+                    const int ci = sb + i < ns ? sb + i : ns - 1;          // clamped: masked below
+                    const bool sup = nms_suppresses<MODE>(L.sbox[4 * ci], L.sbox[4 * ci + 1], L.sbox[4 * ci + 2],
+                                                          L.sbox[4 * ci + 3], L.sarea[ci], mb, iou_thr);
+                    const unsigned long long cm = __ballot(sup && jv && lane > i && sb + i < ns);
+                    if (lane == 0) L.colmask[i] = cm;
+                }
+                __syncthreads();
+                if (wid == 0) {
+                    unsigned long long alive = __ballot(jv);
+#pragma unroll
+                    for (int q = 0; q < NMS_T / 64; ++q) alive &= ~L.deadm[q];
+                    // (every lane holds the same value: make that explicit so the walk below stays on the scalar unit)
+                    alive = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32)) << 32) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive & 0xFFFFFFFFull));
+                    const unsigned long long mycm = L.colmask[lane];
+                    const int cm_lo = (int)(unsigned)(mycm & 0xFFFFFFFFull), cm_hi = (int)(unsigned)(mycm >> 32);
+                    unsigned long long keptm = 0ull;
+                    int cnt = 0;
+                    const int room = max_det - nk;
+                    while (alive != 0ull && cnt < room) {
+                        const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(cm_lo, i);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane(cm_hi, i);
+                        keptm |= 1ull << i;
+                        ++cnt;
+                        alive &= ~(((unsigned long long)hi << 32) | (unsigned long long)lo);
+                        alive &= ~(1ull << i);
+                    }
+                    if ((keptm >> lane) & 1ull) {
+                        const int pos = nk + __popcll(keptm & ((1ull << lane) - 1ull));
+                        L.kbox[4 * pos] = mb.x1; L.kbox[4 * pos + 1] = mb.y1;
+                        L.kbox[4 * pos + 2] = mb.x2; L.kbox[4 * pos + 3] = mb.y2;
+                        L.karea[pos] = mb.area;
+                        L.kidx[pos] = msrc;
+                    }
+                    if (lane == 0) L.s_nk = nk + cnt;
+                }
+                __syncthreads();
+                nk = L.s_nk;
             }
             __syncthreads();
             if (L.s_nk >= max_det) break;
@@ -582,7 +604,19 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(
         __syncthreads();
         if (MODE != 0) break;            // aladdin: one pass over the truncated list
     }
-    if (tid == 0) out_count[img] = L.s_nk;
+    // ---- output: row k = the reference's row for source box kidx[k] (all threads, off the serial chain) ----
+    __syncthreads();
+    const int nkf = L.s_nk;
+    for (int k = tid; k < nkf; k += NMS_T) {
+        const int src = L.kidx[k];
+        float cls, sc, x1, y1, x2, y2;
+        NmsBox tmp;
+        nms_load<MODE>(bx + (int64_t)src * 6, cls, sc, x1, y1, x2, y2, tmp);
+        float* o = orow + (int64_t)k * 6;
+        o[0] = cls; o[1] = sc; o[2] = x1; o[3] = y1; o[4] = x2; o[5] = y2;
+        oidx[k] = src;
+    }
+    if (tid == 0) out_count[img] = nkf;
 }
 
 extern "C" size_t y5m_nms_workspace_bytes(int B, int64_t N) {
