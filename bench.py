@@ -125,7 +125,12 @@ def detect_leg(dev, B=128, size=1280, iters=5):
     anchors = (torch.tensor(config.ANCHORS).float().view(3, -1, 2) / torch.tensor([8., 16., 32.]).view(3, 1, 1)).to(dev)
     N = sum(t.shape[1] * t.shape[2] * t.shape[3] for t in logits)
     out = {}
-    for name, (thr, iou) in {"detect.py (0.25, 0.45)": (0.25, 0.45), "eval (0.01, 0.6)": (0.01, 0.6)}.items():
+    regimes = {"detect.py (0.25, 0.45)": (0.25, 0.45), "eval (0.01, 0.6)": (0.01, 0.6),
+               "worst case: obj ~ N(0,1), all-pass regime (i), (0.25, 0.45)": (0.25, 0.45)}
+    for name, (thr, iou) in regimes.items():
+        if name.startswith("worst"):
+            for t in logits:                       # regime (i) of SURVEY 8d: sigmoid(obj) ~ 0.5, (nearly) every box passes
+                t[..., 4] = (t[..., 4] + 5.0) * 0.5
         for _ in range(2):
             boxes = cells_to_bboxes(logits, anchors, [8, 16, 32], is_pred=True, to_list=False)
             rows, idx, cnt = nms_batched(boxes, iou, thr, 300)
