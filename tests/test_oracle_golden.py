@@ -174,3 +174,45 @@ def test_oracle_nms_aladdin_matches_reference(golden):
         thr, iou, mid, md = g[f"{name}/par"].tolist()
         keep = cnative.nms_aladdin(g[f"{name}/in"], iou, thr, "midpoint" if mid else "corners", int(md))
         assert keep.tolist() == g[f"{name}/keep"].tolist(), name
+
+
+def test_g10_config0_reference_recipe(golden):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case, my_loss_vs_ultra_loss.py:26-33: seed 355,
+    4x3x640x640 uniform images, 12 labels) through the oracle: train-mode logits + ComputeLoss, then the detect
+    path (eval forward, decode, NMS at 0.01 / 0.6 / 300), against values produced by the real reference."""
+    g = golden("g10_config0")
+    torch.manual_seed(355)
+    images = torch.rand((4, 3, 640, 640))
+    np.testing.assert_allclose(images.reshape(-1)[::4801].numpy(), g["img_sample"], rtol=0, atol=0)
+    sd = synth_state_dict()
+    labels = torch.from_numpy(g["labels"])
+    with torch.no_grad():
+        o = model_ref.forward(sd, images, training=True)
+        for i in range(3):
+            got = o[i].reshape(-1).numpy()[::int(g[f"o{i}_step"])][:4096]
+            ref = g[f"o{i}_sample"]
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (i, np.abs(got - ref).max())
+        loss, _ = loss_ref.compute_loss_ultra(o, labels, sd["head.anchors"])
+        np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+        oe = model_ref.forward(sd, images, training=False)
+        boxes = loss_ref.cells_to_bboxes(oe, sd["head.anchors"], [8, 16, 32], is_pred=True)
+        np.testing.assert_allclose(boxes[0, ::97, 1].numpy(), g["eval_obj_sample"], rtol=1e-5, atol=1e-6)
+        kept = loss_ref.non_max_suppression(boxes.numpy(), 0.6, 0.01, 300)
+    assert [len(k[1]) for k in kept] == g["eval_nms_counts"].tolist()
+
+
+def test_g7_large_batch_first_step(golden):
+    """B=16 @ 320x320 train-mode logits + ComputeLoss of the first step through the oracle, against the real
+    reference (the fixture the GPU large-batch tests are checked with)."""
+    g = golden("g7_large_step")
+    B, H, W = [int(v) for v in g["shape"]]
+    x = synth_images(B, H, W, seed="img/rank0")
+    sd = synth_state_dict()
+    with torch.no_grad():
+        o = model_ref.forward(sd, x, training=True)
+        for i in range(3):
+            got = o[i].reshape(-1).numpy()[::int(g[f"o{i}_step"])][:4096]
+            ref = g[f"o{i}_sample"]
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (i, np.abs(got - ref).max())
+        loss, _ = loss_ref.compute_loss_ultra(o, torch.from_numpy(g["targets"]), sd["head.anchors"])
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
