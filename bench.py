@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s (this box's device copy measures 5.3-5.5 TB/s)
 FWD_GFLOP_PER_IMAGE_640 = 48.872
 
 
@@ -238,10 +239,19 @@ def main():
     }
     if not args.no_roofline:
         fams = {}
+        cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
+        esz = 2 if args.dtype == "bf16" else 4
         for _ in range(2):
-            for k, (m_, n_) in step.profile_step(images, targets).items():
+            fam, convs = step.profile_step(images, targets, detail=True)
+            for k, (m_, n_) in fam.items():
                 a, b = fams.get(k, (0.0, 0))
                 fams[k] = (a + m_, b + n_)
+            for ms_, a in convs:
+                c = cls["pointwise" if a.th * a.tw == 1 else "spatial"]
+                c[0] += ms_
+                c[1] += 2.0 * a.M * a.N * a.K
+                c[2] += float(a.M) * (a.K / (a.th * a.tw) + a.N) * esz + float(a.N) * a.K * esz
+                c[3] += 1
         eng = model._engine_for(images)
         fwd_flops = eng.conv_flops()
         stem = eng.layers[0]
@@ -260,6 +270,19 @@ def main():
             "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1),
             "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
             "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
+            # the same launches split by what bounds them: k x k taps (MFMA) vs 1x1 (HBM: every input and output
+            # element moves once, M*(Cin+Cout) elements + the weights)
+            "by_class": {
+                "spatial_convs(taps>1)": {"bound": "mfma", "launches_per_step": cls["spatial"][3] // 2,
+                                          "ms_per_step": round(cls["spatial"][0] / 2, 3),
+                                          "achieved_TFLOPs": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9, 1),
+                                          "frac": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)},
+                "pointwise_convs(1x1)": {"bound": "hbm", "launches_per_step": cls["pointwise"][3] // 2,
+                                         "ms_per_step": round(cls["pointwise"][0] / 2, 3),
+                                         "achieved_GBps": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6, 1),
+                                         "achieved_TFLOPs": round(cls["pointwise"][1] / max(cls["pointwise"][0], 1e-9) / 1e9, 1),
+                                         "frac": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
+            },
         }
     if world == 1 and not args.no_detect:
         del step, images

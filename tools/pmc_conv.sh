@@ -6,7 +6,7 @@ ARGS="$@"
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
-           "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+           "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o p -- python tools/conv_bench.py $ARGS 20 > $OUT/g$i.log 2>&1
 done
@@ -19,7 +19,7 @@ for f in glob.glob("gpurun_out/pmc/g*/**/*counter_collection.csv", recursive=Tru
         k = r["Kernel_Name"].split("(")[0][-50:]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
-    if "conv_igemm" in k or "wgrad" in k:
+    if "conv_igemm" in k or "wgrad" in k or "conv_pw" in k:
         print(k)
         for c, v in sorted(d.items()):
             print(f"   {c:28s} {v:.4g}")

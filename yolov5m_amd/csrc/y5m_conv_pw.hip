@@ -33,10 +33,27 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // output stores of group g drain under the MFMAs of group g+1 instead of being waited for.
 // BNR: EPI_DGRAD launch that also emits the BatchNorm-backward reduction partials of the gradient it
 // finishes (y5m_conv_args.bn_part): the per-lane sums live in the same registers the forward statistics use.
+// Local channel (within the workgroup's chunk) of accumulator register 0 of fragment `a` for the lanes with
+// fq = lane >> 4 (the same function places the weight rows: A row rho of fragment a holds channel
+// pw_lch(a, rho >> 2) + (rho & 3)).
+//   PERM (default): fragments are paired; the lanes fq = 0..3 of a pixel hold channels p*32 + fq*8 + [0,8) of
+//     pair p = a >> 1, so ONE store instruction writes 64 contiguous bytes per pixel (16 B per lane, the four
+//     lanes of a pixel adjacent). With the lane-contiguous layout below the L2 received 21 B per write request
+//     (PMC: 7.4 M write requests for 157 MB, 72 % of all its requests) and the stores cost 40 % of the kernel.
+//   !PERM: a lane holds 4*NCF consecutive channels (48 B runs, 48 B apart): kept for the BNR epilogue, whose
+//     per-lane producer selection needs a lane's channels on one side of bn_split.
+template <int NCF, bool PERM>
+__device__ __forceinline__ constexpr int pw_lch(int a, int fq) {
+    if (!PERM) return fq * (4 * NCF) + a * 4;
+    const int p = a >> 1;
+    return (2 * p + 1 < NCF) ? p * 32 + fq * 8 + (a & 1) * 4 : p * 32 + fq * 4;
+}
+
 template <int NCF, int KS, int EPI, bool OLD, bool BNR>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams P, const int nchunks, const int nstreams,
                                                                const int ngroups, const int stat_rows) {
     constexpr int NC = NCF * 16;
+    constexpr bool PERM = !BNR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NCF][KS][64 lanes] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -54,17 +71,20 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
     // ---- weights -> LDS in A-fragment order (once) -------------------------------------------------
     for (int f = wid; f < NCF * KS; f += PW_THREADS / 64) {
         const int a = f / KS, s = f - a * KS;
-        const int ch = n0 + (fr >> 2) * (4 * NCF) + a * 4 + (fr & 3);
+        const int ch = n0 + pw_lch<NCF, PERM>(a, fr >> 2) + (fr & 3);
         const u32x4 v = *reinterpret_cast<const u32x4*>(W + (size_t)ch * P.Kp + s * 32 + fq * 8);
         *reinterpret_cast<u32x4*>(smem + ((size_t)f * 64 + lane) * 16) = v;
     }
     __syncthreads();
 
-    const int cbase = n0 + fq * (4 * NCF);          // the lane's 4*NCF consecutive output channels
+    const int cbase = n0 + fq * (4 * NCF);          // (!PERM) the lane's 4*NCF consecutive output channels
     float sc[EPI == EPI_AFFINE_ACT ? 4 * NCF : 1], sh[EPI == EPI_AFFINE_ACT ? 4 * NCF : 1];
     if constexpr (EPI == EPI_AFFINE_ACT) {
 #pragma unroll
-        for (int j = 0; j < 4 * NCF; ++j) { sc[j] = P.scale[cbase + j]; sh[j] = P.shift[cbase + j]; }
+        for (int j = 0; j < 4 * NCF; ++j) {
+            const int c = n0 + pw_lch<NCF, PERM>(j >> 2, fq) + (j & 3);
+            sc[j] = P.scale[c]; sh[j] = P.shift[c];
+        }
     }
     constexpr bool SUMS = EPI == EPI_RAW_STATS || BNR;
     float ssum[SUMS ? 4 * NCF : 1], ssq[SUMS ? 4 * NCF : 1];
@@ -101,14 +121,14 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
     // one 16-pixel group: x fragments in xr, prefetch of the stream's next group into xp
     auto process = [&](const u32x4 (&xr)[KS], u32x4 (&xp)[KS], int g) __attribute__((always_inline)) {
         const size_t p = (size_t)g * 16 + fr;
-        bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + p * P.ldout + cbase;
+        bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + p * P.ldout + n0;     // + pw_lch(a, fq): the lane's channels
         // read-modify-write / residual operand of THIS group first, then the next group's x fragments:
         // the wait for `old` then leaves the prefetch in flight
         u32x2 old[OLD ? NCF : 1];
         if constexpr (OLD) {
-            const bf16_t* src = (EPI == EPI_DGRAD && !P.res) ? o : reinterpret_cast<const bf16_t*>(P.res) + p * P.ldres + cbase;
+            const bf16_t* src = (EPI == EPI_DGRAD && !P.res) ? o : reinterpret_cast<const bf16_t*>(P.res) + p * P.ldres + n0;
 #pragma unroll
-            for (int a = 0; a < NCF; ++a) old[a] = *reinterpret_cast<const u32x2*>(src + a * 4);
+            for (int a = 0; a < NCF; ++a) old[a] = *reinterpret_cast<const u32x2*>(src + pw_lch<NCF, PERM>(a, fq));
         }
         {
             const int gn = g + nstreams;
@@ -128,7 +148,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
                                                                  __builtin_bit_cast(bf16x8_t, xr[s]), acc[a], 0, 0, 0);
             }
 
-        // ---- epilogue: lane = pixel p, channels cbase + a*4 + r ------------------------------------
+        // ---- epilogue: lane = pixel p, channels n0 + pw_lch(a, fq) + r --------------------------------
+        u32x2 qa[NCF];
 #pragma unroll
         for (int a = 0; a < NCF; ++a) {
             float v[4] = {acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
@@ -150,7 +171,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
             u32x2 q;
             q.x = f32x2_to_bf16x2(v[0], v[1]);
             q.y = f32x2_to_bf16x2(v[2], v[3]);
-            *reinterpret_cast<u32x2*>(o + a * 4) = q;
+            qa[a] = q;
             if constexpr (BNR) {
                 if (bn_scp) {
                     const u32x2 yq = *reinterpret_cast<const u32x2*>(bn_yb + p * bn_ld + bn_c + a * 4);
@@ -165,6 +186,21 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
                         ssq[a * 4 + r] += dt * yv[r];
                     }
                 }
+            }
+        }
+        // stores: one 16-byte piece per fragment pair (PERM: the 4 lanes of a pixel write 64 contiguous bytes)
+#pragma unroll
+        for (int a = 0; a < NCF; a += 2) {
+            if (a + 1 < NCF) {
+                if constexpr (PERM) {
+                    const u32x4 q4 = {qa[a].x, qa[a].y, qa[a + 1].x, qa[a + 1].y};
+                    *reinterpret_cast<u32x4*>(o + pw_lch<NCF, PERM>(a, fq)) = q4;
+                } else {
+                    *reinterpret_cast<u32x2*>(o + pw_lch<NCF, PERM>(a, fq)) = qa[a];
+                    *reinterpret_cast<u32x2*>(o + pw_lch<NCF, PERM>(a + 1, fq)) = qa[a + 1];
+                }
+            } else {
+                *reinterpret_cast<u32x2*>(o + pw_lch<NCF, PERM>(a, fq)) = qa[a];
             }
         }
     };
@@ -199,8 +235,9 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
             if (fr == 0) {
 #pragma unroll
                 for (int j = 0; j < 4 * NCF; ++j) {
-                    red[(wid * 2 + 0) * NC + fq * (4 * NCF) + j] = ssum[j];
-                    red[(wid * 2 + 1) * NC + fq * (4 * NCF) + j] = ssq[j];
+                    const int c = pw_lch<NCF, PERM>(j >> 2, fq) + (j & 3);
+                    red[(wid * 2 + 0) * NC + c] = ssum[j];
+                    red[(wid * 2 + 1) * NC + c] = ssq[j];
                 }
             }
             __syncthreads();
@@ -297,6 +334,7 @@ static bool pw_eligible(const ConvParams& P, int dtype) {
     if (!pointwise || !dense_out) return 0;
     if (P.Cin % 16 != 0 || P.Cin > 192 || P.Cin <= 32 || P.N % 48 != 0 || P.M % 16 != 0) return 0;
     if (P.res && P.ldres % 4 != 0) return 0;
+    if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return 0;      // 16-byte output pieces
     if (P.bn_part && (P.bn_split % 48 != 0 || P.bn_ldy % 4 != 0 || (P.bn_y2 && P.bn_ldy2 % 4 != 0))) return 0;
     const int KS = (P.Cin + 31) / 32;
     if (KS * 32 > P.Kp) return 0;

@@ -324,9 +324,10 @@ class NativeTrainStep:
         self.d_step.fill_(step)
         self._graph = None                         # captured scalars (lr, betas) may have changed
 
-    def profile_step(self, images, targets):
+    def profile_step(self, images, targets, detail=False):
         """One EAGER step with a HIP event pair around every launch (recorded on the launch stream).
-        Returns {kernel family: (total ms, launches)}."""
+        Returns {kernel family: (total ms, launches)}; with detail=True also the list of (ms, y5m_conv_args) of
+        every forward-conv / data-gradient launch, for per-shape rooflines."""
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
         tl = []
@@ -341,4 +342,15 @@ class NativeTrainStep:
         for kind, e0, e1 in tl:
             ms, n = fam.get(kind, (0.0, 0))
             fam[kind] = (ms + e0.elapsed_time(e1), n + 1)
-        return fam
+        if not detail:
+            return fam
+        # the timeline is pack + fwd + [loss] + bwd + [optimizer], one entry per op
+        items = list(eng.pack) + list(eng.fwd) + [None] + list(eng.bwd) + [None]
+        convs = []
+        for (kind, e0, e1), item in zip(tl, items):
+            if item is None or kind != "conv_igemm":
+                continue
+            d = getattr(item[0], "__defaults__", None)
+            if d:
+                convs.append((e0.elapsed_time(e1), d[0]))
+        return fam, convs
