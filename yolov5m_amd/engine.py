@@ -16,6 +16,7 @@ Memory plan (all resident in HBM, sized for 288 GB):
 """
 import ctypes
 
+import os
 import torch
 
 from . import _lib
@@ -101,8 +102,9 @@ class Engine:
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
         # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
         # so it runs ahead of the side stream instead of ping-ponging with it (each cross-stream wait costs
-        # ~10-15 us of dependency latency inside a hipGraph); 0.63 GB per slot at B=64 / 640^2; measured: more than 2 slots buys nothing
-        self.nslots = max(2, int(os.environ.get("Y5M_SLOTS", "2")))
+        # ~10-15 us of dependency latency inside a hipGraph); 0.63 GB per slot at B=64 / 640^2; with the weight gradient forked after the data gradient 3 slots measure
+        # 0.35 ms/step better than 2 (and than 4)
+        self.nslots = max(2, int(os.environ.get("Y5M_SLOTS", "3")))
         self.lazy_residual = os.environ.get("Y5M_LAZY_RES", "1") != "0"
         # BN-backward reduction fused into the gradient's last data-gradient launch (y5m_conv_args.bn_part):
         # "1" pointwise launches only, "all" every eligible launch, "0" off. OFF by default -- measured at
@@ -775,6 +777,25 @@ class Engine:
                     self.bwd_marks.append((len(self.bwd), name, addr))
             for sl in range(self.nslots):
                 self.bwd.append((self._join_op(sl), ()))
+            if os.environ.get("Y5M_WGRAD_AFTER_DGRAD", "1") == "1":
+                # fork the weight gradient AFTER the layer's data-gradient launches: it then runs next to the following
+                # layer's HBM-bound BatchNorm backward instead of next to the MFMA-bound data gradient it would only
+                # share the matrix cores with (measured 30.83 -> 30.14 ms/step). The dy slot it reads is not rewritten
+                # before the join of that slot, which precedes the BatchNorm backward two layers further on.
+                out, i = [], 0
+                while i < len(self.bwd):
+                    op = self.bwd[i]
+                    if getattr(op[0], "kind", None) == "wgrad":
+                        j = i + 1
+                        while j < len(self.bwd) and getattr(self.bwd[j][0], "kind", None) == "conv_igemm":
+                            out.append(self.bwd[j])
+                            j += 1
+                        out.append(op)
+                        i = j
+                    else:
+                        out.append(op)
+                        i += 1
+                self.bwd = out
 
     # ------------------------------------------------------------------ side-stream overlap (backward)
     def _next_slot(self):
