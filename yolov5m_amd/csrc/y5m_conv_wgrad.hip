@@ -369,7 +369,15 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
             ks = (pwb + base - 1) / base;
         }
         else if (C::TC <= 16) ks = (2048 + base - 1) / base;
-        else ks = (sbk && NFR != 6 && C::THREADS == 256 ? 1024 : resident) / base;   // floor: never more blocks than fit at once (SB: 4 per CU)
+        else {
+            // Y5M_WGRAD_RES_PCT: share of the one-round block budget. Alone on the GPU a full round is best; in the step
+            // the kernel runs NEXT TO the following layer's BatchNorm backward (engine.py), and half a round -- one
+            // block per CU for the 96x48 wave tile -- is: 25 / 38 / 50 / 62 / 75 / 100 / 150 % = +2.3 / +0.2 / 0 / +0.15 /
+            // +0.1 / +0.35 / +0.5 ms per step
+            static int res_pct = -1;
+            if (res_pct < 0) { const char* e = getenv("Y5M_WGRAD_RES_PCT"); res_pct = e ? atoi(e) : 50; }
+            ks = (sbk && NFR != 6 && C::THREADS == 256 ? 1024 : resident) * res_pct / 100 / base;   // floor: never more blocks than fit at once (SB: 4 per CU)
+        }
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
         P.ksplit = ks < 1 ? 1 : ks;
