@@ -78,16 +78,19 @@ def test_forward_bf16_vs_oracle(mode):
         assert err < 3.0 * floor + 0.03, (mode, err, floor)
 
 
-@pytest.mark.parametrize("variant", ["default", "bnred_all", "unfused"])
+@pytest.mark.parametrize("variant", ["default", "bnred_all", "unfused", "early_fork"])
 def test_train_step_grads_f32_golden(golden, variant, monkeypatch):
     """default engine plan; every optional graph-level fusion ON (BatchNorm-backward reduction fused into the
-    last data gradient of every eligible layer); every one OFF (no merged C3 pair, no lazy residual)"""
+    last data gradient of every eligible layer); every one OFF (no merged C3 pair, no lazy residual); the weight
+    gradient forked BEFORE the data gradient with a 2-slot dy ring (the schedule before the fork was moved)"""
     from yolov5m_amd.ultralytics_loss import ComputeLoss
     if variant == "bnred_all":
         monkeypatch.setenv("Y5M_BNRED", "all")
         monkeypatch.setenv("Y5M_WGRAD_SLICES", "1")       # and the non-atomic pointwise weight gradients
     elif variant == "unfused":
         monkeypatch.setenv("Y5M_MERGE_C3", "0"); monkeypatch.setenv("Y5M_LAZY_RES", "0"); monkeypatch.setenv("Y5M_OVERLAP", "0")
+    elif variant == "early_fork":
+        monkeypatch.setenv("Y5M_WGRAD_AFTER_DGRAD", "0"); monkeypatch.setenv("Y5M_SLOTS", "2")
     g = golden("g5_model")
     m = _model("f32")
     m.train()
