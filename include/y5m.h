@@ -115,6 +115,17 @@ int y5m_build_targets(const float* targets, int nt, const int32_t* d_nt, int nt_
  * grad[i] (same shape as p[i], may be NULL for forward only) receives d(loss_out[0])/d(p[i]),
  * fully overwritten. ws: y5m_compute_loss_workspace_bytes(). */
 size_t y5m_compute_loss_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int nt_max);
+/* Gradient-producing variant for a consumer that knows the gradient's structure (the native train step): of grad only
+ * the rows of the cells a target row hit are written (zeros + objectness + box / class terms); every cell's objectness
+ * gradient goes to a compact plane of the workspace. Same loss_out as y5m_compute_loss. */
+int y5m_compute_loss_sparse(const float* const p[3], float* const grad[3], int B, int naxs, const int* ny, const int* nx,
+                            int nc, const y5m_targets tg[3], int nt_max, const float balance[3], float lambda_box,
+                            float lambda_obj, float lambda_cls, float* loss_out, void* ws, size_t ws_bytes, void* stream);
+/* device pointers, inside a y5m_compute_loss workspace of these dimensions, of the three per-cell owner tables
+ * ([B*naxs*ny*nx] int32: index of the LAST target row that hit the cell, -1 = none) and objectness-gradient planes
+ * ([B*naxs*ny*nx] f32, written by the gradient-producing calls); valid after a y5m_compute_loss[_sparse] call */
+int y5m_compute_loss_owner_ptrs(void* ws, int B, int naxs, const int* ny, const int* nx, int nt_max, int32_t* owner_out[3],
+                                float* gobj_out[3]);
 int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int naxs, const int* ny,
                      const int* nx, int nc, const y5m_targets tg[3], int nt_max,
                      const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
@@ -299,6 +310,12 @@ int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int 
 /* d(loss)/d(logits) (B,naxs,ny,nx,nch) f32 -> head conv output gradient [B*ny*nx][ldp] + bias grad */
 int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
                        float* dbias, int dtype, void* stream);
+/* The same result for a gradient written by y5m_compute_loss / y5m_compute_loss_sparse (ultralytics_loss.py:60-120):
+ * that tensor is zero outside channel 4 (objectness) of every cell and the rows of the cells a target row hit. `owner`
+ * and `gobj` are the loss workspace's per-cell tables of that scale (y5m_compute_loss_owner_ptrs): only those two
+ * planes and the owned rows of dlogits are read instead of all 5+nc floats of every cell. naxs == 3, ldp % 4 == 0. */
+int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* owner, const float* gobj, int B, int naxs, int ny, int nx,
+                              int nch, void* dyp, int ldp, float* dbias, int dtype, void* stream);
 /* optimizer (train.py:61 Adam(lr, weight_decay) + training_utils.py:118 clip_grad_norm_(10)) */
 size_t y5m_adam_workspace_bytes(void);
 int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, void* stream);

@@ -354,3 +354,55 @@ def test_nms_aladdin_golden_and_oracle(golden):
         pos = {id(r): i for i, r in enumerate(lst)}
         assert [pos[id(r)] for r in kept] == cnative.nms_aladdin(bx, 0.45, 0.25, fmt, md).tolist(), (N, md, fmt)
     assert non_max_suppression_aladdin([], 0.5, 0.5) == []
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_sparse_head_gradient_path_equals_dense(anchors, dtype):
+    """The native step's head-gradient path -- y5m_compute_loss_sparse (writes only the rows of the cells a target hit +
+    a compact objectness-gradient plane) followed by y5m_head_grad_pack_sparse -- against y5m_compute_loss +
+    y5m_head_grad_pack: same loss, packed rows bit-identical, bias gradient equal up to summation order. Targets include
+    duplicates of one cell (their rows accumulate) and scales whose pixel count is not a multiple of 64."""
+    import ctypes
+    from yolov5m_amd import _lib
+    from yolov5m_amd.ultralytics_loss import ComputeLoss, _Workspace
+    L = _lib.lib()
+    B, nt_max = 3, 64
+    shapes = [(20, 12), (10, 6), (5, 3)]
+    p = [uniform(f"shp/{i}", (B, 3, ny, nx, 85), -3.0, 3.0).to(DEV) for i, (ny, nx) in enumerate(shapes)]
+    t = synth_labels(B, 6, seed="shp")
+    t = torch.cat([t, t[:4]]).to(DEV)                          # duplicated targets: several rows on the same cells
+    lf = ComputeLoss(_StubModel(anchors))
+    st = _lib.stream_ptr()
+    res = {}
+    for mode, fn in (("dense", L.y5m_compute_loss), ("sparse", L.y5m_compute_loss_sparse)):
+        ws = _Workspace(DEV, B, 3, shapes, nt_max)
+        grads = [torch.full_like(q, 123.0) for q in p]          # the sparse variant leaves most of it untouched
+        _lib.check(L.y5m_build_targets(_lib.ptr(t), t.shape[0], None, nt_max, _lib.ptr(lf.anchors), 3, ws.ny, ws.nx,
+                                       float(lf.anchor_t), ws.tg, _lib.ptr(ws.bt_ws), ws.bt_ws_bytes, st), "bt")
+        _lib.check(fn(_lib.ptr_array(p), _lib.ptr_array(grads), B, 3, ws.ny, ws.nx, lf.nc, ws.tg, nt_max,
+                      _lib.float_array(lf.balance), float(lf.lambda_box), float(lf.lambda_obj), float(lf.lambda_class),
+                      _lib.ptr(ws.loss_out), _lib.ptr(ws.loss_ws), ws.loss_ws_bytes, st), mode)
+        own, gob = (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)()
+        _lib.check(L.y5m_compute_loss_owner_ptrs(_lib.ptr(ws.loss_ws), B, 3, ws.ny, ws.nx, nt_max, own, gob), "owner")
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        code = _lib.BF16 if dtype == "bf16" else _lib.F32
+        packed, bias = [], []
+        for i, (ny, nx) in enumerate(shapes):
+            d = torch.full((B * ny * nx, 256), 7.0, dtype=tdt, device=DEV)
+            b = torch.zeros(255, device=DEV)
+            if mode == "dense":
+                _lib.check(L.y5m_head_grad_pack(_lib.ptr(grads[i]), B, 3, ny, nx, 85, _lib.ptr(d), 256, _lib.ptr(b), code, st), "dense")
+                assert int((grads[i][..., 5:].abs().sum(-1) > 0).sum()) > 0      # there ARE target rows on this scale
+            else:
+                _lib.check(L.y5m_head_grad_pack_sparse(_lib.ptr(grads[i]), ctypes.c_void_p(own[i]), ctypes.c_void_p(gob[i]), B, 3,
+                                                       ny, nx, 85, _lib.ptr(d), 256, _lib.ptr(b), code, st), "sparse")
+                assert float((grads[i] == 123.0).float().mean()) > 0.5           # untouched outside the target rows
+            packed.append(d); bias.append(b)
+        res[mode] = (ws.loss_out.clone(), packed, bias)
+    assert torch.equal(res["dense"][0], res["sparse"][0])
+    for i in range(3):
+        d0, d1 = res["dense"][1][i].float(), res["sparse"][1][i].float()
+        # identical arithmetic; only cells hit by SEVERAL target rows accumulate (f32 atomics) in a run-dependent order
+        assert float((d0 == d1).float().mean()) > 0.999, i
+        np.testing.assert_allclose(d1.cpu().numpy(), d0.cpu().numpy(), rtol=1e-2 if dtype == "bf16" else 1e-5, atol=1e-9)
+        np.testing.assert_allclose(res["sparse"][2][i].cpu().numpy(), res["dense"][2][i].cpu().numpy(), rtol=1e-5, atol=1e-7)

@@ -161,6 +161,7 @@ struct LossScale {
     float* rowlbox;        // [cap] 1 - giou
     float* rowcls;         // [cap] sum_c bce
     float* objpart;        // [nblk] per-block partial sums of the objectness BCE
+    float* gobj;           // [cells] d loss / d objectness logit (compact copy of channel 4 of grad)
     int ny, nx, cap, nblk;
     int64_t cells;
     float balance;
@@ -171,6 +172,8 @@ struct LossArgs {
     int B, naxs, nc, nch;
     float lam_box, lam_obj, lam_cls;
     int dense_mode;        // 1: reference loss.py semantics (ignore cells keep target -1, empty mean = NaN)
+    int sparse_grad;       // 1: grad rows are written ONLY for owned cells (the rest of grad is left untouched): the
+                           //    consumer reads gobj + owner + those rows (y5m_head_grad_pack_sparse)
 };
 
 __device__ __forceinline__ float bce_logits(float x, float t) {   // BCEWithLogits, pos_weight = 1
@@ -261,6 +264,21 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A) {
         gobj = (sigmoidf_(x) - t) * (S.balance * A.lam_obj * (float)A.B / (float)S.cells);
     }
     if (GRAD) {
+        if (cell < S.cells) S.gobj[cell] = gobj;
+    }
+    if (GRAD && A.sparse_grad) {
+        // rows of owned cells only: zeros + the objectness gradient, the target rows then accumulate onto them
+        const int ow = cell < S.cells ? S.owner[cell] : -1;
+        unsigned long long owned = __ballot(ow >= 0);
+        while (owned) {
+            const int cl = __ffsll((long long)owned) - 1;
+            owned &= owned - 1ull;
+            const float go = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gobj), cl));
+            float* dst = S.grad + (c0 + cl) * A.nch;
+            if (lane < A.nch) dst[lane] = lane == 4 ? go : 0.0f;
+            if (lane + 64 < A.nch) dst[lane + 64] = 0.0f;
+        }
+    } else if (GRAD) {
         gsm[wid][lane] = gobj;                       // same-wave LDS traffic is in order: no barrier
         if (c0 < S.cells) {
             const int ncell = (int)((S.cells - c0) < 64 ? (S.cells - c0) : 64);
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(LossArgs A, float* 
     }
 }
 
-static size_t loss_ws_layout(int B, int naxs, const int* ny, const int* nx, int nt_max, size_t off[3][5], int nblk[3]) {
+static size_t loss_ws_layout(int B, int naxs, const int* ny, const int* nx, int nt_max, size_t off[3][6], int nblk[3]) {
     size_t cur = 0;
     const size_t cap = (size_t)5 * naxs * (nt_max > 0 ? nt_max : 1);
     for (int s = 0; s < 3; ++s) {
@@ -345,22 +363,35 @@ static size_t loss_ws_layout(int B, int naxs, const int* ny, const int* nx, int 
         off[s][2] = cur; cur += y5m_align(cap * 4);
         off[s][3] = cur; cur += y5m_align(cap * 4);
         off[s][4] = cur; cur += y5m_align((size_t)(nblk[s] > 0 ? nblk[s] : 1) * 4);
+        off[s][5] = cur; cur += y5m_align(cells * 4);
     }
     return cur + 256;
 }
 
 extern "C" size_t y5m_compute_loss_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int nt_max) {
-    size_t off[3][5]; int nblk[3];
+    size_t off[3][6]; int nblk[3];
     return loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
+}
+
+extern "C" int y5m_compute_loss_owner_ptrs(void* ws, int B, int naxs, const int* ny, const int* nx, int nt_max,
+                                           int32_t* owner_out[3], float* gobj_out[3]) {
+    Y5M_REQUIRE(ws && owner_out && gobj_out, "null");
+    size_t off[3][6]; int nblk[3];
+    loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
+    for (int s = 0; s < 3; ++s) {
+        owner_out[s] = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + off[s][0]);
+        gobj_out[s] = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + off[s][5]);
+    }
+    return Y5M_OK;
 }
 
 static int run_loss(const float* const p[3], float* const grad[3], const float* const dense[3], int B, int naxs,
                     const int* ny, const int* nx, int nc, const y5m_targets tg[3], int nt_max, const float balance[3],
                     float lambda_box, float lambda_obj, float lambda_cls, float* loss_out, void* ws, size_t ws_bytes,
-                    hipStream_t st) {
+                    hipStream_t st, int sparse_grad = 0) {
     Y5M_REQUIRE(B >= 1 && naxs >= 1 && nc >= 1, "bad dims");
     Y5M_REQUIRE(5 + nc <= 128, "5+nc must be <= 128 (one wave holds a logit row in two registers)");
-    size_t off[3][5]; int nblk[3];
+    size_t off[3][6]; int nblk[3];
     const size_t need = loss_ws_layout(B, naxs, ny, nx, nt_max, off, nblk);
     if (ws_bytes < need) { y5m_set_error("compute_loss ws too small"); return Y5M_EWS; }
     char* w = reinterpret_cast<char*>(ws);
@@ -368,6 +399,7 @@ static int run_loss(const float* const p[3], float* const grad[3], const float* 
     A.B = B; A.naxs = naxs; A.nc = nc; A.nch = 5 + nc;
     A.lam_box = lambda_box; A.lam_obj = lambda_obj; A.lam_cls = lambda_cls;
     A.dense_mode = dense ? 1 : 0;
+    A.sparse_grad = sparse_grad;
     bool want_grad = grad != nullptr;
     for (int s = 0; s < 3; ++s) if (p[s] && !(grad && grad[s])) want_grad = false;
     int max_blk = 0;
@@ -381,6 +413,7 @@ static int run_loss(const float* const p[3], float* const grad[3], const float* 
         S.rowlbox = reinterpret_cast<float*>(w + off[s][2]);
         S.rowcls = reinterpret_cast<float*>(w + off[s][3]);
         S.objpart = reinterpret_cast<float*>(w + off[s][4]);
+        S.gobj = reinterpret_cast<float*>(w + off[s][5]);
         S.ny = ny[s]; S.nx = nx[s]; S.cap = cap; S.nblk = nblk[s];
         S.cells = (int64_t)B * naxs * ny[s] * nx[s];
         S.balance = balance[s];
@@ -412,6 +445,17 @@ extern "C" int y5m_compute_loss(const float* const p[3], float* const grad[3], i
                                 float* loss_out, void* ws, size_t ws_bytes, void* stream) {
     return run_loss(p, grad, nullptr, B, naxs, ny, nx, nc, tg, nt_max, balance, lambda_box, lambda_obj, lambda_cls,
                     loss_out, ws, ws_bytes, y5m_stream(stream));
+}
+
+// Same loss; of grad only the rows of the cells a target row hit are written (zeros + objectness + box / class terms),
+// the objectness gradient of every cell goes to the workspace's compact plane (y5m_compute_loss_owner_ptrs).
+extern "C" int y5m_compute_loss_sparse(const float* const p[3], float* const grad[3], int B, int naxs, const int* ny,
+                                       const int* nx, int nc, const y5m_targets tg[3], int nt_max,
+                                       const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                       float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    Y5M_REQUIRE(grad != nullptr, "y5m_compute_loss_sparse is the gradient-producing variant");
+    return run_loss(p, grad, nullptr, B, naxs, ny, nx, nc, tg, nt_max, balance, lambda_box, lambda_obj, lambda_cls,
+                    loss_out, ws, ws_bytes, y5m_stream(stream), 1);
 }
 
 // =================================================================================================
@@ -460,7 +504,7 @@ static size_t dense_tables_bytes(int rows) {
 static int dense_nt(int rows_max, int naxs) { return (rows_max + 5 * naxs - 1) / (5 * naxs) + 1; }
 
 extern "C" size_t y5m_compute_loss_dense_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int rows_max) {
-    size_t off[3][5]; int nblk[3];
+    size_t off[3][6]; int nblk[3];
     return dense_tables_bytes(5 * naxs * dense_nt(rows_max, naxs)) + loss_ws_layout(B, naxs, ny, nx, dense_nt(rows_max, naxs), off, nblk) + 256;
 }
 

@@ -97,6 +97,7 @@ class Engine:
         self.nc, self.naxs = model.head.nc, model.head.naxs
         self.nch = 5 + self.nc
         self.fwd, self.bwd = [], []
+        self.head_owner = None          # per scale (owner table, objectness-gradient plane) of the loss workspace, see _head
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
@@ -670,14 +671,23 @@ class Engine:
             self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), N, x.C, 1, 1, 1, 0, 1, 1, 0, 1, 1, _lib.ptr(wd),
                        wd.shape[0], wd.shape[1], ldp, dt)
 
-            def backward(lay=lay, x=x, P=P, wd=wd, ldp=ldp, M=M, N=N):
+            def backward(lay=lay, x=x, P=P, wd=wd, ldp=ldp, M=M, N=N, i=i):
                 ops = []
                 slot = self._next_slot()
                 scratch = self.scratch2[slot]
                 ops.append((self._join_op(slot), ()))
-                ops.append((lambda: _lib.check(
-                    L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch),
-                                         ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack"), ()))
+                def pack(lay=lay, x=x, P=P, scratch=scratch, ldp=ldp, i=i):
+                    # head_owner: set by NativeTrainStep when lay.gout was written by y5m_compute_loss (zero outside the
+                    # objectness channel and the target rows): the sparse pack reads ~1/85 of it
+                    ow = self.head_owner[i] if self.head_owner is not None else None
+                    if ow:
+                        _lib.check(L.y5m_head_grad_pack_sparse(_lib.ptr(lay.gout), ctypes.c_void_p(ow[0]), ctypes.c_void_p(ow[1]),
+                                                               x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch), ldp,
+                                                               _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack_sparse")
+                    else:
+                        _lib.check(L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch),
+                                                        ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack")
+                ops.append((pack, ()))
                 wa = WgradArgs()
                 wa.zeros = _lib.zero_page(self.dev).data_ptr()
                 wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
@@ -924,6 +934,7 @@ class Engine:
         Fills the model's flat gradient buffer (reference parameter layout)."""
         assert self.training
         if grads is not None:
+            self.head_owner = None               # arbitrary upstream gradients: dense head pack
             for lay, g in zip(self.heads, grads):
                 lay.gout.copy_(g)
         self._run(self.bwd)

@@ -12,6 +12,7 @@ Two entry points:
 """
 import ctypes
 import math
+import os
 import random
 
 import torch
@@ -143,12 +144,22 @@ class NativeTrainStep:
             self._ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
         ws = self._ws
         grads = eng.head_grad_buffers()
+        sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
+        if sparse and getattr(ws, "owner_ptrs", None) is None:
+            own, gob = (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)()
+            _lib.check(L.y5m_compute_loss_owner_ptrs(_lib.ptr(ws.loss_ws), B, eng.naxs, ws.ny, ws.nx, self.nt_max, own, gob),
+                       "y5m_compute_loss_owner_ptrs")
+            ws.owner_ptrs = [(int(own[i]), int(gob[i])) for i in range(3)]
+        # sparse: the loss writes only the target rows of the dense gradient + a compact objectness plane, and the head
+        # backward packs from those (y5m_head_grad_pack_sparse) instead of walking 85 floats per cell
+        eng.head_owner = ws.owner_ptrs if sparse else None
+        loss_call = L.y5m_compute_loss_sparse if sparse else L.y5m_compute_loss
 
         def loss_ops():
             _lib.check(L.y5m_build_targets(_lib.ptr(self.targets), 0, _lib.ptr(self.d_nt), self.nt_max,
                                            _lib.ptr(lf.anchors), eng.naxs, ws.ny, ws.nx, float(lf.anchor_t), ws.tg,
                                            _lib.ptr(ws.bt_ws), ws.bt_ws_bytes, st), "y5m_build_targets")
-            _lib.check(L.y5m_compute_loss(_lib.ptr_array(outs), _lib.ptr_array(grads), B, eng.naxs, ws.ny, ws.nx,
+            _lib.check(loss_call(_lib.ptr_array(outs), _lib.ptr_array(grads), B, eng.naxs, ws.ny, ws.nx,
                                           lf.nc, ws.tg, self.nt_max, _lib.float_array(lf.balance),
                                           float(lf.lambda_box), float(lf.lambda_obj), float(lf.lambda_class),
                                           _lib.ptr(ws.loss_out), _lib.ptr(ws.loss_ws), ws.loss_ws_bytes, st),
