@@ -312,10 +312,12 @@ int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, in
                        float* dbias, int dtype, void* stream);
 /* The same result for a gradient written by y5m_compute_loss / y5m_compute_loss_sparse (ultralytics_loss.py:60-120):
  * that tensor is zero outside channel 4 (objectness) of every cell and the rows of the cells a target row hit. `owner`
- * and `gobj` are the loss workspace's per-cell tables of that scale (y5m_compute_loss_owner_ptrs): only those two
- * planes and the owned rows of dlogits are read instead of all 5+nc floats of every cell. naxs == 3, ldp % 4 == 0. */
-int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* owner, const float* gobj, int B, int naxs, int ny, int nx,
-                              int nch, void* dyp, int ldp, float* dbias, int dtype, void* stream);
+ * and `gobj` are the loss workspace's per-cell tables of that scale (y5m_compute_loss_owner_ptrs), `bagg` / `count` the
+ * scale's target rows (y5m_targets, cap = their capacity): only the objectness plane and the hit rows of dlogits are
+ * read instead of all 5+nc floats of every cell. naxs == 3, ldp % 4 == 0. */
+int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* owner, const float* gobj, const int32_t* bagg,
+                              const int32_t* count, int cap, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
+                              float* dbias, int dtype, void* stream);
 /* optimizer (train.py:61 Adam(lr, weight_decay) + training_utils.py:118 clip_grad_norm_(10)) */
 size_t y5m_adam_workspace_bytes(void);
 int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, void* stream);

@@ -394,7 +394,8 @@ def test_sparse_head_gradient_path_equals_dense(anchors, dtype):
                 _lib.check(L.y5m_head_grad_pack(_lib.ptr(grads[i]), B, 3, ny, nx, 85, _lib.ptr(d), 256, _lib.ptr(b), code, st), "dense")
                 assert int((grads[i][..., 5:].abs().sum(-1) > 0).sum()) > 0      # there ARE target rows on this scale
             else:
-                _lib.check(L.y5m_head_grad_pack_sparse(_lib.ptr(grads[i]), ctypes.c_void_p(own[i]), ctypes.c_void_p(gob[i]), B, 3,
+                _lib.check(L.y5m_head_grad_pack_sparse(_lib.ptr(grads[i]), ctypes.c_void_p(own[i]), ctypes.c_void_p(gob[i]),
+                                                       _lib.ptr(ws.bagg[i]), _lib.ptr(ws.count[i]), ws.cap, B, 3,
                                                        ny, nx, 85, _lib.ptr(d), 256, _lib.ptr(b), code, st), "sparse")
                 assert float((grads[i] == 123.0).float().mean()) > 0.5           # untouched outside the target rows
             packed.append(d); bias.append(b)

@@ -1048,16 +1048,18 @@ extern "C" int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny,
     return Y5M_OK;
 }
 
-// Sparse-aware variant for a gradient produced by y5m_compute_loss: zero outside channel 4 of every cell and the
-// rows of the owned cells. One wave owns 64 consecutive pixel rows; lane l first fetches row l's three objectness
-// gradients and owners, then the wave writes the rows one by one: an un-owned row is ONE 8-byte (bf16) store per
-// lane with three non-zero values, an owned row (a few thousand per step) takes the dense path. Reads ~1/85 of the
-// tensor the dense kernel walks (0.48 -> ~0.1 ms per step at B=64).
+// Sparse-aware variant for a gradient produced by y5m_compute_loss[_sparse]: zero outside channel 4 of every cell and
+// the rows of the cells a target row hit.
+//   (1) head_grad_pack_obj_kernel: every packed row = zeros + the three objectness gradients (from the loss
+//       workspace's compact plane). One wave owns 64 consecutive pixel rows: lane l fetches row l's three values
+//       (coalesced), then the wave writes the rows one by one, ONE 8-byte (bf16) store per lane and row.
+//   (2) head_grad_rows_kernel: one wave per target row j that owns its cell (owner[cell] == j: every hit cell has exactly
+//       one such row): the 5+nc accumulated values of that cell's dense row overwrite the packed row's box / class
+//       columns (channel 4 is already there) and go to the bias gradient.
+// Reads ~1/85 of the tensor the dense kernel walks (0.48 -> ~0.1 ms per step at B=64).
 template <typename T>
-__global__ __launch_bounds__(256) void head_grad_pack_sparse_kernel(const float* __restrict__ dl, const int32_t* __restrict__ owner,
-                                                                   const float* __restrict__ gobj,
-                                                                   int B, int naxs, int64_t hw, int nch, T* __restrict__ dyp,
-                                                                   int ldp, float* __restrict__ dbias) {
+__global__ __launch_bounds__(256) void head_grad_pack_obj_kernel(const float* __restrict__ gobj, int B, int naxs, int64_t hw, int nch,
+                                                                T* __restrict__ dyp, int ldp, float* __restrict__ dbias) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t M = (int64_t)B * hw;
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
@@ -1065,75 +1067,80 @@ __global__ __launch_bounds__(256) void head_grad_pack_sparse_kernel(const float*
     const int64_t m = m0 + lane;
     const bool rv = m < M;
     float go[3] = {0.f, 0.f, 0.f};
-    int ow[3] = {-1, -1, -1};
     if (rv) {
         const int64_t b = m / hw, pix = m - b * hw;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int64_t cell = (b * naxs + a) * hw + pix;
-            go[a] = gobj[cell];                        // (= dl[cell*nch + 4], from the compact plane: coalesced)
-            ow[a] = owner[cell];
-        }
+        for (int a = 0; a < 3; ++a) go[a] = gobj[(b * naxs + a) * hw + pix];
     }
-    const int N = naxs * nch;
-    // where the three objectness columns sit in the 4-column pieces of the fast path
+    // the three objectness columns inside the 4-column pieces: lane ca >> 2, slot ca & 3
     const int c0 = 4, c1 = nch + 4, c2 = 2 * nch + 4;
+    const bool l0 = lane == (c0 >> 2), l1 = lane == (c1 >> 2), l2 = lane == (c2 >> 2);
+    const bool writer = 4 * lane < ldp;
     const int nrow = (int)((M - m0) < 64 ? (M - m0) : 64);
     for (int r = 0; r < nrow; ++r) {
-        const int o0 = __builtin_amdgcn_readlane(ow[0], r), o1 = __builtin_amdgcn_readlane(ow[1], r),
-                  o2 = __builtin_amdgcn_readlane(ow[2], r);
         const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go[0]), r));
         const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go[1]), r));
         const float g2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go[2]), r));
-        T* drow = dyp + (m0 + r) * ldp;
-        if ((o0 & o1 & o2) < 0) {                      // no target on this pixel: three non-zero values in the row
-            if (4 * lane < ldp) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int col = 4 * lane + k;
-                    v[k] = col == c0 ? g0 : (col == c1 ? g1 : (col == c2 ? g2 : 0.f));
-                }
-                store4<T>(drow + 4 * lane, v);
-            }
-        } else {
-            const int64_t mr = m0 + r, b = mr / hw, pix = mr - b * hw;
-            for (int col = lane; col < ldp; col += 64) {
-                float v = 0.f;
-                if (col < N) {
-                    const int a = col / nch, ch = col - a * nch;
-                    const int oa = a == 0 ? o0 : (a == 1 ? o1 : o2);
-                    if (oa >= 0) {
-                        v = dl[((b * naxs + a) * hw + pix) * nch + ch];
-                        if (dbias) atomicAdd(&dbias[col], v);
-                    } else if (ch == 4) {
-                        v = a == 0 ? g0 : (a == 1 ? g1 : g2);
-                    }
-                }
-                drow[col] = from_f32<T>(v);
-            }
+        for (int k = 0; k < 4; ++k) {
+            if (l0 && k == (c0 & 3)) v[k] = g0;
+            if (l1 && k == (c1 & 3)) v[k] = g1;
+            if (l2 && k == (c2 & 3)) v[k] = g2;
         }
+        if (writer) store4<T>(dyp + (m0 + r) * ldp + 4 * lane, v);
     }
     if (dbias) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float sacc = wave_sum(rv && ow[a] < 0 ? go[a] : 0.f);      // (owned cells were added on the dense path)
+            const float sacc = wave_sum(go[a]);
             if (lane == 0) atomicAdd(&dbias[a * nch + 4], sacc);
         }
     }
 }
-extern "C" int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* owner, const float* gobj, int B, int naxs, int ny,
-                                         int nx, int nch, void* dyp, int ldp, float* dbias, int dtype, void* stream) {
-    Y5M_REQUIRE(naxs == 3 && nch >= 5, "sparse head gradient: 3 anchors per scale");
+template <typename T>
+__global__ __launch_bounds__(256) void head_grad_rows_kernel(const float* __restrict__ dl, const int32_t* __restrict__ owner,
+                                                            const int32_t* __restrict__ bagg, const int32_t* __restrict__ count,
+                                                            int naxs, int ny, int nx, int nch, T* __restrict__ dyp, int ldp,
+                                                            float* __restrict__ dbias) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= *count) return;
+    const int4 q = reinterpret_cast<const int4*>(bagg)[j];              // (b, a, gj, gi)
+    const int64_t hw = (int64_t)ny * nx, pix = (int64_t)q.z * nx + q.w;
+    const int64_t cell = ((int64_t)q.x * naxs + q.y) * hw + pix;
+    if (owner[cell] != j) return;                                       // another row of the same cell does it
+    const float* row = dl + cell * nch;
+    T* drow = dyp + ((int64_t)q.x * hw + pix) * ldp + q.y * nch;
+    const float v0 = lane < nch ? row[lane] : 0.f;
+    const float v1 = lane + 64 < nch ? row[lane + 64] : 0.f;
+    if (lane < nch && lane != 4) {
+        drow[lane] = from_f32<T>(v0);
+        if (dbias) atomicAdd(&dbias[q.y * nch + lane], v0);
+    }
+    if (lane + 64 < nch) {
+        drow[lane + 64] = from_f32<T>(v1);
+        if (dbias) atomicAdd(&dbias[q.y * nch + lane + 64], v1);
+    }
+}
+extern "C" int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* owner, const float* gobj, const int32_t* bagg,
+                                         const int32_t* count, int cap, int B, int naxs, int ny, int nx, int nch, void* dyp,
+                                         int ldp, float* dbias, int dtype, void* stream) {
+    Y5M_REQUIRE(naxs == 3 && nch >= 5 && nch <= 128, "sparse head gradient: 3 anchors per scale, 5+nc <= 128");
     Y5M_REQUIRE(ldp <= 256 && ldp >= naxs * nch && ldp % 4 == 0, "head dims: naxs*nch <= ldp <= 256, ldp % 4 == 0");
-    Y5M_REQUIRE(owner != nullptr && gobj != nullptr, "owner / objectness-gradient tables missing");
+    Y5M_REQUIRE(owner && gobj && bagg && count && cap >= 0, "owner / objectness-gradient / target-row tables missing");
     hipStream_t st = y5m_stream(stream);
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)naxs * nch * 4, st) != hipSuccess) { y5m_set_error("memset dbias"); return Y5M_ELAUNCH; }
     const int64_t M = (int64_t)B * ny * nx;
     const unsigned grid = (unsigned)((M + 255) / 256);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_sparse_kernel<T>, dim3(grid), dim3(256), 0, st, dlogits, owner, gobj, B, naxs,
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_obj_kernel<T>, dim3(grid), dim3(256), 0, st, gobj, B, naxs,
                                          (int64_t)ny * nx, nch, (T*)dyp, ldp, dbias);)
-    Y5M_CHECK_LAUNCH("head_grad_pack_sparse_kernel");
+    Y5M_CHECK_LAUNCH("head_grad_pack_obj_kernel");
+    if (cap > 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_rows_kernel<T>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, st, dlogits,
+                                             owner, bagg, count, naxs, ny, nx, nch, (T*)dyp, ldp, dbias);)
+        Y5M_CHECK_LAUNCH("head_grad_rows_kernel");
+    }
     return Y5M_OK;
 }
 

@@ -97,7 +97,7 @@ class Engine:
         self.nc, self.naxs = model.head.nc, model.head.naxs
         self.nch = 5 + self.nc
         self.fwd, self.bwd = [], []
-        self.head_owner = None          # per scale (owner table, objectness-gradient plane) of the loss workspace, see _head
+        self.head_owner = None          # per scale (owner, objectness-gradient plane, target rows, row count, capacity) of the loss, see _head
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
@@ -682,6 +682,7 @@ class Engine:
                     ow = self.head_owner[i] if self.head_owner is not None else None
                     if ow:
                         _lib.check(L.y5m_head_grad_pack_sparse(_lib.ptr(lay.gout), ctypes.c_void_p(ow[0]), ctypes.c_void_p(ow[1]),
+                                                               ctypes.c_void_p(ow[2]), ctypes.c_void_p(ow[3]), ow[4],
                                                                x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch), ldp,
                                                                _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack_sparse")
                     else:

@@ -149,7 +149,7 @@ class NativeTrainStep:
             own, gob = (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)()
             _lib.check(L.y5m_compute_loss_owner_ptrs(_lib.ptr(ws.loss_ws), B, eng.naxs, ws.ny, ws.nx, self.nt_max, own, gob),
                        "y5m_compute_loss_owner_ptrs")
-            ws.owner_ptrs = [(int(own[i]), int(gob[i])) for i in range(3)]
+            ws.owner_ptrs = [(int(own[i]), int(gob[i]), ws.bagg[i].data_ptr(), ws.count[i].data_ptr(), ws.cap) for i in range(3)]
         # sparse: the loss writes only the target rows of the dense gradient + a compact objectness plane, and the head
         # backward packs from those (y5m_head_grad_pack_sparse) instead of walking 85 floats per cell
         eng.head_owner = ws.owner_ptrs if sparse else None
