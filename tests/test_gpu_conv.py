@@ -99,6 +99,27 @@ PW_CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 36), (1, 64, 64), (3, 24, 40)])
+def test_stem_streaming_kernel(shape):
+    """the stem geometry (3x3 / stride 1 / pad 1 over the 16-channel space-to-depth image, 48 output channels) runs on the
+    tapped mode of the streaming kernel in bf16: training statistics epilogue and the folded-BN inference epilogue,
+    image borders on every side, several images per launch"""
+    from yolov5m_amd import ops
+    B, H, W = shape
+    x = _q(_rand((B, 16, H, W), 41), "bf16")
+    x[:, 12:] = 0                                             # the 4 padding channels of the space-to-depth input
+    w = _q(_rand((48, 16, 3, 3), 42, -0.2, 0.2), "bf16")
+    ref = F.conv2d(x, w, None, 1, 1)
+    got, s1, s2 = ops.conv_forward_stats(x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    assert _relerr(got.cpu(), ref) < TOL["bf16"]
+    np.testing.assert_allclose(s1.cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=5e-2)
+    np.testing.assert_allclose(s2.cpu().numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=2e-3, atol=5e-2)
+    sc, sh = _rand((48,), 43, 0.5, 1.5), _rand((48,), 44, -0.2, 0.2)
+    ref2 = F.silu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got2 = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 1, "bf16", scale=sc.to(DEV), shift=sh.to(DEV), act=True).cpu()
+    assert _relerr(got2, ref2) < TOL["bf16"]
+
+
 @pytest.mark.parametrize("case", PW_CASES)
 def test_pointwise_forward_stats(case):
     from yolov5m_amd import ops

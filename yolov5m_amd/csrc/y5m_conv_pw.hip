@@ -49,7 +49,12 @@ __device__ __forceinline__ constexpr int pw_lch(int a, int fq) {
     return (2 * p + 1 < NCF) ? p * 32 + fq * 8 + (a & 1) * 4 : p * 32 + fq * 4;
 }
 
-template <int NCF, int KS, int EPI, bool OLD, bool BNR>
+// TAP: the 3x3 / stride-1 / pad-1 conv over a 16-channel input (the stem on the space-to-depth image: K = 9 taps x 16
+// channels = 144 -> KS = 5 steps, the last half step padding): the same barrier-free stream, but every 16-byte piece
+// of an x fragment comes from its own tap (k = s*32 + fq*8 -> tap k >> 4 = 2s + (fq >> 1), channel half (fq & 1) * 8)
+// with its own image-border test (out-of-image taps read the zero page). The tiled kernel spends 3 K steps per
+// 128-pixel tile here and runs at 40 % of the HBM rate this layer is bound by (839 MB in 0.43 ms).
+template <int NCF, int KS, int EPI, bool OLD, bool BNR, bool TAP = false>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams P, const int nchunks, const int nstreams,
                                                                const int ngroups, const int stat_rows) {
     constexpr int NC = NCF * 16;
@@ -108,14 +113,40 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
     // ---- x fragment loads -----------------------------------------------------------------------------
     const ptrdiff_t zoff = reinterpret_cast<const bf16_t*>(P.zeros) - X;
     const bool klast_ok = (KS - 1) * 32 + fq * 8 < P.Cin;        // K % 32 == 16: upper half of the last step is padding
+    // TAP: per K step, this lane's tap offset (dy, dx) and channel half; tap 9 (padding) is marked by dy = 1 << 20
+    int tdy[TAP ? KS : 1], tdx[TAP ? KS : 1];
+    if constexpr (TAP) {
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const int tap = 2 * st + (fq >> 1);
+            tdy[st] = tap < 9 ? tap / 3 - 1 : (1 << 20);
+            tdx[st] = tap % 3 - 1;
+        }
+    }
+    const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
     auto load_x = [&](u32x4 (&xr)[KS], int g) __attribute__((always_inline)) {
         const size_t p = (size_t)g * 16 + fr;
+        if constexpr (TAP) {
+            int t, x, b, y;
+            fast_divmod((int)p, P.Wg, rcpW, t, x);
+            fast_divmod(t, P.Hg, rcpH, b, y);
+            const ptrdiff_t base = (ptrdiff_t)p * P.ldin + (fq & 1) * 8;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const int yy = y + tdy[st], xx = x + tdx[st];
+                const bool ok = (unsigned)yy < (unsigned)P.Hin && (unsigned)xx < (unsigned)P.Win;
+                ptrdiff_t off = base + (ptrdiff_t)(tdy[st] * P.Win + tdx[st]) * P.ldin;
+                off = ok ? off : zoff;
+                xr[st] = *reinterpret_cast<const u32x4*>(X + off);
+            }
+        } else {
         const ptrdiff_t off = (ptrdiff_t)(p * P.ldin + fq * 8);
 #pragma unroll
         for (int s = 0; s < KS - 1; ++s) xr[s] = *reinterpret_cast<const u32x4*>(X + off + s * 32);   // (nontemporal: measured slower)
         ptrdiff_t last = off + (KS - 1) * 32;
         asm("" : "+v"(last));
         xr[KS - 1] = *reinterpret_cast<const u32x4*>(X + (klast_ok ? last : zoff));
+        }
     };
 
     // one 16-pixel group: x fragments in xr, prefetch of the stream's next group into xp
@@ -256,7 +287,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
 static int g_pw = -1;          // Y5M_CONV_PW=0 routes every layer through the tiled kernel (A/B runs)
 static int g_pw_occ = -1;      // Y5M_CONV_PW_OCC: workgroups per CU of the persistent grid
 
-template <int NCF, int KS, int EPI, bool OLD, bool BNR = false>
+template <int NCF, int KS, int EPI, bool OLD, bool BNR = false, bool TAP = false>
 static int launch_pw(const ConvParams& P, hipStream_t st) {
     constexpr int NC = NCF * 16;
     if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 2; }      // (re-swept with the weight gradient forked after the data gradient: 2 beats 4 by ~0.15 ms/step)
@@ -275,7 +306,7 @@ static int launch_pw(const ConvParams& P, hipStream_t st) {
     if (sblocks < 8) return 0;                                       // tiny problem: leave it to the tiled kernel
     const int nstreams = sblocks * 4;
     const size_t lds = (size_t)NCF * KS * 64 * 16 + ((EPI == EPI_RAW_STATS || BNR) ? 4 * 2 * NC * sizeof(float) : 0);
-    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, BNR>;
+    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, BNR, TAP>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -308,7 +339,26 @@ extern "C" int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype) {
     return pw_eligible(P, dtype) ? 1 : 0;
 }
 
+// the stem: 3x3 / stride 1 / pad 1 over 16 input channels, 48 output channels, dense output (training statistics or the
+// folded-BN inference epilogue without residual)
+static bool tap_eligible(const ConvParams& P, int dtype) {
+    static int on = -1;                              // Y5M_CONV_PW_STEM=0: leave the stem to the tiled kernel (A/B runs)
+    if (on < 0) { const char* e = getenv("Y5M_CONV_PW_STEM"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || dtype != Y5M_BF16) return 0;
+    const bool stem = P.th == 3 && P.tw == 3 && P.sy == 1 && P.sx == 1 && P.dh0 == -1 && P.dw0 == -1 && P.dhs == 1 && P.dws == 1 &&
+                      P.Hin == P.Hg && P.Win == P.Wg && P.Cin == 16 && P.ldin == 16 && P.N == 48 && P.K == 144 && P.Kp >= 160;
+    const bool dense_out = P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 && P.Hout == P.Hg && P.Wout == P.Wg;
+    if (!stem || !dense_out || P.M % 16 != 0 || P.res || P.bn_part) return 0;
+    if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return 0;
+    if (P.epi == EPI_RAW_STATS) return P.stats != nullptr && (P.M + CV_BM - 1) / CV_BM >= 8;
+    return P.epi == EPI_AFFINE_ACT;
+}
+
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
+    if (tap_eligible(P, dtype)) {
+        if (P.epi == EPI_RAW_STATS) return launch_pw<3, 5, EPI_RAW_STATS, false, false, true>(P, st);
+        return launch_pw<3, 5, EPI_AFFINE_ACT, false, false, true>(P, st);
+    }
     if (!pw_eligible(P, dtype)) return 0;
     const int KS = (P.Cin + 31) / 32;
     // channel chunk per workgroup: 96 when it divides N, else 48
