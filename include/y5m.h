@@ -198,6 +198,10 @@ typedef struct {
 
 int y5m_conv_tile_n(int N);   /* channel tile (48 or 96) the library uses for N output channels */
 int y5m_conv(const y5m_conv_args* args, int dtype, void* stream);
+/* n data-gradient problems over the same pixel grid, input tensor and output width (the 4 parity classes of a stride-2
+ * convolution's data gradient) as ONE launch: their tiles are interleaved so that the shared input is fetched once.
+ * Any other set of problems is run as n y5m_conv calls. */
+int y5m_conv_multi(const y5m_conv_args* args, int n, int dtype, void* stream);
 /* 1 when y5m_conv would run this launch on the pointwise streaming kernel (HBM-bound), 0 for the tiled one */
 int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype);
 

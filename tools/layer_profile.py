@@ -29,7 +29,12 @@ for (kind, e0, e1), item in zip(tl, lists):
         continue
     fn = item[0]
     d = getattr(fn, "__defaults__", None)
-    if kind == "conv_igemm" and d:
+    if kind == "conv_igemm" and d and hasattr(d[0], "_length_"):
+        parts = list(d[0])
+        fl = sum(2.0 * a.M * a.N * a.K for a in parts)
+        a = parts[-1]
+        rows.append((ms, f"conv  M={a.M:8d} N={a.N:4d} K={sum(q.K for q in parts):5d} taps=multi x{len(parts)} s=2 epi={a.epi} acc={a.accumulate}  {fl/ms/1e9:7.1f} TF/s"))
+    elif kind == "conv_igemm" and d:
         a = d[0]
         fl = 2.0 * a.M * a.N * a.K
         rows.append((ms, f"conv  M={a.M:8d} N={a.N:4d} K={a.K:5d} taps={a.th}x{a.tw} s={a.sy} epi={a.epi} acc={a.accumulate}  {fl/ms/1e9:7.1f} TF/s"))

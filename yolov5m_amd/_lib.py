@@ -110,6 +110,7 @@ _SIGS = {
     "y5m_conv_tile_n": (c_int, [c_int]),
     "y5m_conv_is_pointwise": (c_int, [c_void_p, c_int]),
     "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),
+    "y5m_conv_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y5m_pack_weights_batched": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),

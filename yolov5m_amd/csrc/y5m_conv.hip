@@ -2,6 +2,7 @@
 // See y5m_conv.h for the tiling / layout description.
 #include "y5m_conv.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -22,8 +23,16 @@ __device__ __forceinline__ constexpr int cv_pch(int a, int rho) {
     return (2 * (a >> 1) + 1 < NF) ? (a >> 1) * 32 + (rho >> 2) * 8 + (a & 1) * 4 + (rho & 3) : (a >> 1) * 32 + rho;
 }
 
+// logical tile id of hardware workgroup `bid` (workgroup b runs on XCD b % 8): workgroups with consecutive logical
+// ids run on ONE XCD, so tiles that share operands (same pixel tile, different channel tile / parity class) meet in
+// that XCD's L2
+__device__ __forceinline__ int xcd_logical_id(int bid, int nblk) {
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
 template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams P) {
+__device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int lid) {
     constexpr int THREADS = WM * WN * 64, RSTEP = THREADS / 8;   // RSTEP: tile rows staged per pass (8 chunks per row)
     constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -36,11 +45,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid % WM, wn = wid / WM;
 
-    // XCD-aware tile order: blocks that share a pixel tile (same tile_m, different tile_n) get
-    // consecutive logical ids on ONE XCD so the activation tile is served from that XCD's L2.
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    // XCD-aware tile order (xcd_logical_id): blocks that share a pixel tile (same tile_m, different tile_n) have
+    // consecutive logical ids
     const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -398,6 +404,55 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
     }
 }
 
+template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams P) {
+    conv_igemm_body<T, WM, WN, MF, NF, DB, BNR>(P, xcd_logical_id(blockIdx.x, gridDim.x));
+}
+
+// Up to 4 problems of the same tiling in ONE launch (the parity classes of a stride-2 data gradient: same dY, same
+// pixel grid, 1 / 2 / 2 / 4 taps). Logical id -> (tile, class) with the class fastest: the classes of a tile run on
+// one XCD at the same time, so dY comes from HBM once instead of once per class (separate launches of 80-315 MB
+// tensors do not meet in a 4 MB L2).
+struct ConvMulti { ConvParams p[4]; int n; };        // p MUST stay the first member (see conv_igemm_multi_kernel)
+static_assert(offsetof(ConvMulti, p) == 0, "kernarg layout");
+template <typename T, int WM, int WN, int MF, int NF>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_multi_kernel(const ConvMulti MP) {
+    const int lid = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int cls = lid % MP.n;
+    // the class's parameter block straight from the kernarg segment (MP is its first and only explicit argument): a
+    // dynamically indexed by-value struct would be copied to scratch, this is a uniform scalar load
+    typedef const __attribute__((address_space(4))) unsigned* kernarg_words_t;
+    static_assert(sizeof(ConvParams) % 4 == 0, "dword copy");
+    constexpr int NW = (int)(sizeof(ConvParams) / 4);
+    const kernarg_words_t src = (kernarg_words_t)__builtin_amdgcn_kernarg_segment_ptr() + cls * NW;
+    ConvParams P;
+    unsigned* dst = reinterpret_cast<unsigned*>(&P);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) dst[i] = src[i];
+    conv_igemm_body<T, WM, WN, MF, NF, false, false>(P, lid / MP.n);
+}
+
+template <typename T, int WM, int WN, int MF, int NF>
+static int launch_conv_multi(ConvMulti& MP, hipStream_t st) {
+    constexpr int BN = WN * NF * 16;
+    int tiles = 0;
+    for (int i = 0; i < MP.n; ++i) {
+        MP.p[i].tiles_m = (MP.p[i].M + CV_BM - 1) / CV_BM;
+        MP.p[i].tiles_n = (MP.p[i].N + BN - 1) / BN;
+        tiles = MP.p[i].tiles_m * MP.p[i].tiles_n;
+    }
+    const size_t lds = (size_t)(CV_BM + BN) * 128;
+    auto kern = conv_igemm_multi_kernel<T, WM, WN, MF, NF>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * MP.n)), dim3(WM * WN * 64), lds, st, MP);
+    Y5M_CHECK_LAUNCH("conv_igemm_multi_kernel");
+    return Y5M_OK;
+}
+
 template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR = false>
 static int launch_conv_db(ConvParams& P, hipStream_t st) {
     constexpr int BN = WN * NF * 16;
@@ -515,4 +570,42 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
         if (r != Y5M_OK) return r;
     }
     return Y5M_OK;
+}
+
+// n <= 4 data-gradient problems (EPI_DGRAD) over the same pixel grid and output width -- the parity classes of a
+// stride-2 convolution's data gradient -- as ONE launch of the tiled kernel (conv_igemm_multi_kernel). Anything that
+// does not fit that pattern falls back to n separate y5m_conv calls, so callers may always use this entry point.
+extern "C" int y5m_conv_multi(const y5m_conv_args* args, int n, int dtype, void* stream) {
+    Y5M_REQUIRE(args && n >= 1, "args");
+    static int on = -1;                              // Y5M_CONV_MULTI=0: always separate launches (A/B runs)
+    if (on < 0) { const char* e = getenv("Y5M_CONV_MULTI"); on = (e && e[0] == '0') ? 0 : 1; }
+    bool ok = on && n >= 2 && n <= 4 && dtype == Y5M_BF16;
+    for (int i = 0; ok && i < n; ++i) {
+        const y5m_conv_args& a = args[i];
+        ok = a.epi == EPI_DGRAD && !a.bn_part && a.M == args[0].M && a.N == args[0].N && a.B == args[0].B &&
+             a.Hg == args[0].Hg && a.Wg == args[0].Wg && a.in == args[0].in && a.ldin == args[0].ldin &&
+             a.Kp % 64 == 0 && a.Kp >= a.K && a.K == a.th * a.tw * a.Cin && a.Cin % 8 == 0 && a.ldin % 8 == 0 &&
+             a.N % 4 == 0 && a.ldout % 4 == 0 && a.zeros != nullptr && a.M == a.B * a.Hg * a.Wg && a.M > 0 &&
+             (size_t)a.B * a.Hin * a.Win * a.ldin * 2 < (1ull << 31) && (size_t)a.Hin * a.Win < (1ull << 22);
+        if (ok) {
+            const int BNt = y5m_conv_tile_n(a.N);
+            ok = a.Np >= (a.N + BNt - 1) / BNt * BNt;
+        }
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const int r = y5m_conv(&args[i], dtype, stream);
+            if (r != Y5M_OK) return r;
+        }
+        return Y5M_OK;
+    }
+    ConvMulti MP;
+    memset(&MP, 0, sizeof(MP));
+    for (int i = 0; i < n; ++i) memcpy(&MP.p[i], &args[i], sizeof(ConvParams));
+    MP.n = n;
+    hipStream_t st = y5m_stream(stream);
+    const int BN = y5m_conv_tile_n(args[0].N);
+    if (BN == 48) return launch_conv_multi<bf16_t, 4, 1, 2, 3>(MP, st);
+    if (BN == 192) return launch_conv_multi<bf16_t, 2, 4, 4, 3>(MP, st);
+    return launch_conv_multi<bf16_t, 2, 2, 4, 3>(MP, st);
 }

@@ -346,7 +346,17 @@ class Engine:
                     if lay.ss == 1:
                         self._bnred_plan(lay.x, a)
                     lay.dgrad_args.append(a)
-                    ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm"), ()))
+                if len(lay.dgrad_args) > 1:
+                    # stride 2: the parity classes read the same dy -- one launch with their tiles interleaved (y5m_conv_multi)
+                    arr = (ConvArgs * len(lay.dgrad_args))()
+                    for i, a in enumerate(lay.dgrad_args):
+                        ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(a), ctypes.sizeof(ConvArgs))
+                    lay.dgrad_multi = arr
+                    ops.append((_kind(lambda arr=arr: _lib.check(L.y5m_conv_multi(arr, len(arr), dt, st()), "y5m_conv_multi(dgrad)"),
+                                      "conv_igemm"), ()))
+                else:
+                    for a in lay.dgrad_args:
+                        ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm"), ()))
                 self._written(lay.x)
             return ops
         self._bwd_stack.append(backward)

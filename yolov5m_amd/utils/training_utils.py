@@ -362,6 +362,10 @@ class NativeTrainStep:
             if item is None or kind != "conv_igemm":
                 continue
             d = getattr(item[0], "__defaults__", None)
-            if d:
+            if d and hasattr(d[0], "_length_"):            # y5m_conv_multi: one launch, several problems (time split by work)
+                ms, parts = e0.elapsed_time(e1), list(d[0])
+                tot = float(sum(a.K for a in parts))
+                convs.extend((ms * a.K / tot, a) for a in parts)
+            elif d:
                 convs.append((e0.elapsed_time(e1), d[0]))
         return fam, convs
