@@ -454,3 +454,34 @@ def test_conv_multi_equals_separate_launches():
         assert float((written == 3.0).float().mean()) < 0.01                  # every output pixel was written
         checked += 1
     assert checked >= 5                                                       # backbone 1/3/5/7 + the two neck downsamples
+
+
+def test_tap48_streaming_kernel():
+    """48-channel 3x3 layers on the tapped streaming kernel: stride-1 forward with statistics (48 -> 48), the inference
+    epilogue with residual, and the stride-1 data gradient with / without accumulation (default on); the stride-2
+    48 -> 96 forward takes it only with Y5M_CONV_PW_TAP48=7 and the tiled kernel otherwise"""
+    from yolov5m_amd import ops
+    B, H, W = 2, 40, 48
+    x = _q(_rand((B, 48, H, W), 51), "bf16")
+    w = _q(_rand((48, 48, 3, 3), 52, -0.1, 0.1), "bf16")
+    ref = F.conv2d(x, w, None, 1, 1)
+    got, s1, s2 = ops.conv_forward_stats(x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    assert _relerr(got.cpu(), ref) < TOL["bf16"]
+    np.testing.assert_allclose(s1.cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=5e-2)
+    w2 = _q(_rand((96, 48, 3, 3), 53, -0.1, 0.1), "bf16")
+    ref2 = F.conv2d(x, w2, None, 2, 1)
+    got2, _, _ = ops.conv_forward_stats(x.to(DEV), w2.to(DEV), 2, 1, "bf16")
+    assert _relerr(got2.cpu(), ref2) < TOL["bf16"]
+    sc, sh = _rand((48,), 54, 0.5, 1.5), _rand((48,), 55, -0.2, 0.2)
+    res = _q(_rand((B, 48, H, W), 56), "bf16")
+    ref3 = F.silu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res
+    got3 = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 1, "bf16", scale=sc.to(DEV), shift=sh.to(DEV), act=True, res=res.to(DEV)).cpu()
+    assert _relerr(got3, ref3) < TOL["bf16"]
+    dy = _q(_rand((B, 48, H, W), 57), "bf16")
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, 1, 1).backward(dy)
+    got4 = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, 1, "bf16").cpu()
+    assert _relerr(got4, xr.grad) < TOL["bf16"]
+    init = _q(_rand((B, 48, H, W), 58), "bf16")
+    got5 = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, 1, "bf16", init=init.to(DEV)).cpu()
+    assert _relerr(got5, xr.grad + init) < TOL["bf16"]

@@ -54,7 +54,7 @@ __device__ __forceinline__ constexpr int pw_lch(int a, int fq) {
 // of an x fragment comes from its own tap (k = s*32 + fq*8 -> tap k >> 4 = 2s + (fq >> 1), channel half (fq & 1) * 8)
 // with its own image-border test (out-of-image taps read the zero page). The tiled kernel spends 3 K steps per
 // 128-pixel tile here and runs at 40 % of the HBM rate this layer is bound by (839 MB in 0.43 ms).
-template <int NCF, int KS, int EPI, bool OLD, bool BNR, bool TAP = false>
+template <int NCF, int KS, int EPI, bool OLD, bool BNR, int TAPC = 0>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams P, const int nchunks, const int nstreams,
                                                                const int ngroups, const int stat_rows) {
     constexpr int NC = NCF * 16;
@@ -113,14 +113,21 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
     // ---- x fragment loads -----------------------------------------------------------------------------
     const ptrdiff_t zoff = reinterpret_cast<const bf16_t*>(P.zeros) - X;
     const bool klast_ok = (KS - 1) * 32 + fq * 8 < P.Cin;        // K % 32 == 16: upper half of the last step is padding
-    // TAP: per K step, this lane's tap offset (dy, dx) and channel half; tap 9 (padding) is marked by dy = 1 << 20
-    int tdy[TAP ? KS : 1], tdx[TAP ? KS : 1];
+    // TAPC > 0 (channels per tap): per K step, this lane's 16-byte piece k0 = st*32 + fq*8 belongs to tap k0 / TAPC at
+    // channel k0 % TAPC (TAPC % 8 == 0: a piece never straddles two taps): element offset from the group's base pixel
+    // and the tap's (dy, dx) for the border test; K padding behind the last tap is marked by dy = 1 << 20
+    constexpr bool TAP = TAPC > 0;
+    int tdy[TAP ? KS : 1], tdx[TAP ? KS : 1], tof[TAP ? KS : 1];
     if constexpr (TAP) {
 #pragma unroll
         for (int st = 0; st < KS; ++st) {
-            const int tap = 2 * st + (fq >> 1);
-            tdy[st] = tap < 9 ? tap / 3 - 1 : (1 << 20);
-            tdx[st] = tap % 3 - 1;
+            const int k0 = st * 32 + fq * 8;
+            const int tap = k0 / TAPC, ch = k0 - tap * TAPC;
+            const int ta = tap / P.tw, tb = tap - ta * P.tw;
+            const bool real = tap < P.th * P.tw;
+            tdy[st] = real ? P.dh0 + ta * P.dhs : (1 << 20);
+            tdx[st] = P.dw0 + tb * P.dws;
+            tof[st] = real ? (tdy[st] * P.Win + tdx[st]) * P.ldin + ch : 0;
         }
     }
     const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
@@ -130,13 +137,13 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
             int t, x, b, y;
             fast_divmod((int)p, P.Wg, rcpW, t, x);
             fast_divmod(t, P.Hg, rcpH, b, y);
-            const ptrdiff_t base = (ptrdiff_t)p * P.ldin + (fq & 1) * 8;
+            y *= P.sy; x *= P.sx;                                  // input position of tap offset (0, 0)
+            const ptrdiff_t base = ((ptrdiff_t)(b * P.Hin + y) * P.Win + x) * P.ldin;
 #pragma unroll
             for (int st = 0; st < KS; ++st) {
                 const int yy = y + tdy[st], xx = x + tdx[st];
                 const bool ok = (unsigned)yy < (unsigned)P.Hin && (unsigned)xx < (unsigned)P.Win;
-                ptrdiff_t off = base + (ptrdiff_t)(tdy[st] * P.Win + tdx[st]) * P.ldin;
-                off = ok ? off : zoff;
+                const ptrdiff_t off = ok ? base + tof[st] : zoff;
                 xr[st] = *reinterpret_cast<const u32x4*>(X + off);
             }
         } else {
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
 static int g_pw = -1;          // Y5M_CONV_PW=0 routes every layer through the tiled kernel (A/B runs)
 static int g_pw_occ = -1;      // Y5M_CONV_PW_OCC: workgroups per CU of the persistent grid
 
-template <int NCF, int KS, int EPI, bool OLD, bool BNR = false, bool TAP = false>
+template <int NCF, int KS, int EPI, bool OLD, bool BNR = false, int TAPC = 0>
 static int launch_pw(const ConvParams& P, hipStream_t st) {
     constexpr int NC = NCF * 16;
     if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 2; }      // (re-swept with the weight gradient forked after the data gradient: 2 beats 4 by ~0.15 ms/step)
@@ -306,7 +313,7 @@ static int launch_pw(const ConvParams& P, hipStream_t st) {
     if (sblocks < 8) return 0;                                       // tiny problem: leave it to the tiled kernel
     const int nstreams = sblocks * 4;
     const size_t lds = (size_t)NCF * KS * 64 * 16 + ((EPI == EPI_RAW_STATS || BNR) ? 4 * 2 * NC * sizeof(float) : 0);
-    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, BNR, TAP>;
+    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, BNR, TAPC>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -339,25 +346,45 @@ extern "C" int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype) {
     return pw_eligible(P, dtype) ? 1 : 0;
 }
 
-// the stem: 3x3 / stride 1 / pad 1 over 16 input channels, 48 output channels, dense output (training statistics or the
-// folded-BN inference epilogue without residual)
-static bool tap_eligible(const ConvParams& P, int dtype) {
-    static int on = -1;                              // Y5M_CONV_PW_STEM=0: leave the stem to the tiled kernel (A/B runs)
+// Tapped streaming mode. (a) the stem: 3x3 / stride 1 / pad 1 over the 16-channel space-to-depth image, 48 output
+// channels; (b) the 48 -> 48 3x3 layers of the 160x160 stage (K = 432 -> 14 K steps): forward / inference epilogue and
+// the stride-1 data gradient (Y5M_CONV_PW_TAP48 bit mask; bit 2 = the stride-2 48 -> 96 forward, off: one 84 KB weight
+// image per CU leaves too few waves). Dense output only.
+static int tap_kind(const ConvParams& P, int dtype) {
+    static int on = -1, on48 = -1;                   // Y5M_CONV_PW_STEM=0: leave the stem to the tiled kernel (A/B runs)
     if (on < 0) { const char* e = getenv("Y5M_CONV_PW_STEM"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || dtype != Y5M_BF16) return 0;
-    const bool stem = P.th == 3 && P.tw == 3 && P.sy == 1 && P.sx == 1 && P.dh0 == -1 && P.dw0 == -1 && P.dhs == 1 && P.dws == 1 &&
-                      P.Hin == P.Hg && P.Win == P.Wg && P.Cin == 16 && P.ldin == 16 && P.N == 48 && P.K == 144 && P.Kp >= 160;
+    if (on48 < 0) { const char* e = getenv("Y5M_CONV_PW_TAP48"); on48 = e ? atoi(e) : 3; }   // measured: bit 0 -0.13, bit 1 -0.08, bit 2 +-0 ms/step
+    if (dtype != Y5M_BF16 || P.th != 3 || P.tw != 3 || P.K != 9 * P.Cin || P.ldin % 8 != 0) return 0;
     const bool dense_out = P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 && P.Hout == P.Hg && P.Wout == P.Wg;
-    if (!stem || !dense_out || P.M % 16 != 0 || P.res || P.bn_part) return 0;
+    if (!dense_out || P.M % 16 != 0 || P.bn_part || P.epi == EPI_HEAD) return 0;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return 0;
-    if (P.epi == EPI_RAW_STATS) return P.stats != nullptr && (P.M + CV_BM - 1) / CV_BM >= 8;
-    return P.epi == EPI_AFFINE_ACT;
+    if (P.res && P.ldres % 4 != 0) return 0;
+    if (P.epi == EPI_RAW_STATS && (!P.stats || (P.M + CV_BM - 1) / CV_BM < 8)) return 0;
+    if ((size_t)P.B * P.Hin * P.Win * P.ldin * 2 >= (1ull << 31)) return 0;          // 32-bit pixel arithmetic in the loader
+    if (on && P.Cin == 16 && P.N == 48 && P.Kp >= 160 && P.sy == 1 && P.sx == 1 && !P.res && !P.accumulate &&
+        (P.epi == EPI_RAW_STATS || P.epi == EPI_AFFINE_ACT))
+        return 16;
+    if (on48 && P.Cin == 48 && (P.N == 48 || P.N == 96) && P.Kp >= 448 && P.sy == P.sx && (P.sy == 1 || P.sy == 2)) {
+        // bit 0: 48 -> 48 forward / inference, bit 1: 48 -> 48 data gradient, bit 2: the stride-2 48 -> 96 forward
+        const int bit = P.N == 96 ? 4 : (P.epi == EPI_DGRAD ? 2 : 1);
+        if (on48 & bit) return 48;
+    }
+    return 0;
+}
+
+template <int NCF, int KS, int TAPC>
+static int launch_tap_epi(const ConvParams& P, hipStream_t st) {
+    if (P.epi == EPI_RAW_STATS) return launch_pw<NCF, KS, EPI_RAW_STATS, false, false, TAPC>(P, st);
+    if (P.epi == EPI_AFFINE_ACT)
+        return P.res ? launch_pw<NCF, KS, EPI_AFFINE_ACT, true, false, TAPC>(P, st) : launch_pw<NCF, KS, EPI_AFFINE_ACT, false, false, TAPC>(P, st);
+    return (P.accumulate || P.res) ? launch_pw<NCF, KS, EPI_DGRAD, true, false, TAPC>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false, false, TAPC>(P, st);
 }
 
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
-    if (tap_eligible(P, dtype)) {
-        if (P.epi == EPI_RAW_STATS) return launch_pw<3, 5, EPI_RAW_STATS, false, false, true>(P, st);
-        return launch_pw<3, 5, EPI_AFFINE_ACT, false, false, true>(P, st);
+    switch (tap_kind(P, dtype)) {
+    case 16: return launch_tap_epi<3, 5, 16>(P, st);
+    case 48: return P.N == 48 ? launch_tap_epi<3, 14, 48>(P, st) : launch_tap_epi<6, 14, 48>(P, st);
+    default: break;
     }
     if (!pw_eligible(P, dtype)) return 0;
     const int KS = (P.Cin + 31) / 32;
