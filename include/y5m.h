@@ -197,6 +197,10 @@ typedef struct {
 } y5m_conv_args;
 
 int y5m_conv_tile_n(int N);   /* channel tile (48 or 96) the library uses for N output channels */
+/* EPI_RAW_STATS: number of partial rows [rows][2][Np] y5m_conv writes into args->stats for this launch (the
+ * caller sizes the buffer with it and passes it to y5m_bn_finalize as tiles_m): one per 128-pixel tile on the
+ * tiled / pointwise kernels, four per 256-pixel tile on the 3x3 halo-patch kernel. */
+int y5m_conv_stats_rows(const y5m_conv_args* args, int dtype);
 int y5m_conv(const y5m_conv_args* args, int dtype, void* stream);
 /* n data-gradient problems over the same pixel grid, input tensor and output width (the 4 parity classes of a stride-2
  * convolution's data gradient) as ONE launch: their tiles are interleaved so that the shared input is fetched once.
@@ -204,6 +208,9 @@ int y5m_conv(const y5m_conv_args* args, int dtype, void* stream);
 int y5m_conv_multi(const y5m_conv_args* args, int n, int dtype, void* stream);
 /* 1 when y5m_conv would run this launch on the pointwise streaming kernel (HBM-bound), 0 for the tiled one */
 int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype);
+/* 1 when y5m_conv would run this launch on the persistent 3x3 halo-patch kernel (bf16, stride 1, >= 64 input channels,
+ * output channels a multiple of 96, image width such that two input patches fit the LDS) */
+int y5m_conv_is_halo(const y5m_conv_args* args, int dtype);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
  * dwgt[n][tap*C + c] += sum_m dy[m][n] * x[pix(m,tap)][c], f32 atomics into a ZEROED packed buffer. */

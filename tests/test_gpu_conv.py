@@ -80,6 +80,66 @@ def test_conv_stats_epilogue(dtype):
     np.testing.assert_allclose(s2.cpu().numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-3, atol=1e-2)
 
 
+# 3x3 / stride-1 layers with >= 64 input channels and N % 96 == 0 run on the persistent halo-patch kernel
+# (y5m_conv_halo.hip) in bf16: 32-channel last slab (C = 96), one and several 64-channel slabs, one and two channel
+# tiles, image borders on all sides with several images per launch, a pixel count that is not a multiple of the
+# 256-pixel tile, fewer pixels than one tile, and more tiles than workgroups (the persistent loop's second round).
+HALO_CASES = [
+    # B, Cin, H, W, Cout
+    (2, 96, 10, 14, 96),
+    (3, 64, 9, 11, 192),
+    (2, 192, 20, 20, 192),
+    (1, 192, 12, 12, 384),
+    (2, 384, 8, 8, 384),
+    (1, 96, 80, 80, 96),
+    (1, 128, 6, 7, 96),
+    (2, 96, 400, 96, 96),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_halo_forward_stats_and_epilogue(case):
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout = case
+    x = _q(_rand((B, Cin, H, W), 61), "bf16")
+    w = _q(_rand((Cout, Cin, 3, 3), 62, -0.1, 0.1), "bf16")
+    ref = F.conv2d(x, w, None, 1, 1)
+    got, s1, s2 = ops.conv_forward_stats(x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    assert ops.LAST_KERNEL == "halo"
+    assert _relerr(got.cpu(), ref) < TOL["bf16"], _relerr(got.cpu(), ref)
+    np.testing.assert_allclose(s1.cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.02 * float(ref.abs().max()) * 8)
+    np.testing.assert_allclose(s2.cpu().numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.05)
+    sc, sh = _rand((Cout,), 63, 0.5, 1.5), _rand((Cout,), 64, -0.2, 0.2)
+    res = _q(_rand((B, Cout, H, W), 65), "bf16")
+    ref2 = F.silu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res
+    got2 = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 1, "bf16", scale=sc.to(DEV), shift=sh.to(DEV), act=True,
+                            res=res.to(DEV)).cpu()
+    assert ops.LAST_KERNEL == "halo"
+    assert _relerr(got2, ref2) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("mode", ["plain", "init", "src"])
+@pytest.mark.parametrize("case", HALO_CASES[:6])
+def test_halo_dgrad(case, mode):
+    """data gradient of the same layers (mirrored taps, transposed weights): plain store, accumulation onto an existing
+    gradient, and the fused residual source"""
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout = case
+    dy = _q(_rand((B, Cout, H, W), 66), "bf16")
+    w = _q(_rand((Cout, Cin, 3, 3), 67, -0.1, 0.1), "bf16")
+    ref = F.conv_transpose2d(dy, w, None, 1, 1)
+    kw = {}
+    if mode != "plain":
+        extra = _q(_rand((B, Cin, H, W), 68), "bf16")
+        ref = ref + extra
+        kw = {"init": extra.to(DEV)} if mode == "init" else {"src": extra.to(DEV)}
+    if Cin % 96 != 0:
+        pytest.skip("data gradient has N = Cin output channels: not a halo shape")
+    got = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, 1, "bf16", **kw).cpu()
+    assert ops.LAST_KERNEL == "halo"
+    assert _relerr(got, ref) < TOL["bf16"], _relerr(got, ref)
+
+
 # short-K pointwise layers take the barrier-free streaming kernel (y5m_conv_pw.hip) in bf16: every
 # (channel chunk, K steps) instance, several chunks per pixel stream, a stream count that does not divide
 # the group count, and one pixel count (4606) that is not a multiple of the 16-pixel group (that layer

@@ -26,7 +26,6 @@ if kind in ("fwd", "dgrad"):
     BN = L.y5m_conv_tile_n(Cout)
     Np = rup(Cout, BN)
     w = (torch.randn(Np * Kp, device=dev) * 0.05).bfloat16()
-    stats = torch.zeros(((M + 127) // 128) * 2 * Np, device=dev)
     a = ConvArgs()
     a.zeros = z.data_ptr()
     a.inp, a.w, a.out = x.data_ptr(), w.data_ptr(), y.data_ptr()
@@ -36,7 +35,9 @@ if kind in ("fwd", "dgrad"):
     a.Hout, a.Wout, a.ldout, a.osy, a.osx = Ho, Wo, Cout, 1, 1
     a.Np = Np
     if kind == "fwd":
-        a.epi, a.stats = EPI_RAW_STATS, stats.data_ptr()
+        a.epi = EPI_RAW_STATS
+        stats = torch.zeros(L.y5m_conv_stats_rows(ctypes.byref(a), BF16) * 2 * Np, device=dev)
+        a.stats = stats.data_ptr()
     else:
         a.epi = EPI_DGRAD
     run = lambda: _lib.check(L.y5m_conv(ctypes.byref(a), BF16, _lib.stream_ptr()), "conv")

@@ -500,8 +500,14 @@ extern "C" int y5m_conv_tile_n(int N) {
 }
 
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st);      // y5m_conv_pw.hip
+int y5m_conv_halo_try(const ConvParams& P, int dtype, hipStream_t st);    // y5m_conv_halo.hip
 
 static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
+    {
+        // 3x3 stride-1 layers with >= 64 input channels: persistent halo-patch kernel (y5m_conv_halo.hip)
+        const int r = y5m_conv_halo_try(P, dtype, st);
+        if (r != 0) return r < 0 ? r : Y5M_OK;
+    }
     {
         // short-K pointwise layers stream through the barrier-free kernel (y5m_conv_pw.hip)
         const int r = y5m_conv_pw_try(P, dtype, st);

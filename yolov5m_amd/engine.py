@@ -198,9 +198,9 @@ class Engine:
             dest.producer = lay
             self._consume(x)
             self._consume(res)
-            tiles_m = (M + 127) // 128
-            self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np)
             a = self._conv_args(x, lay.wf, lay.y.data_ptr(), Ho, Wo, kk, ss, pp, cout, cout, EPI_RAW_STATS, Kp)
+            tiles_m = L.y5m_conv_stats_rows(ctypes.byref(a), dt)      # partial rows this launch writes (kernel dependent)
+            self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np)
             lay.fwd_args = a
             self._stat_users.append(a)
             self._run_conv(self.fwd, a)
@@ -505,8 +505,6 @@ class Engine:
         destA = self._new_act(x.B, x.H, x.W, cout)
         wf = torch.zeros((Np2, Kp), dtype=self.tdt, device=self.dev)
         y2 = torch.zeros((M * N2,), dtype=self.tdt, device=self.dev)
-        tiles_m = (M + 127) // 128
-        self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np2)
         halves = []
         for name, off, dest in ((nameA, 0, destA), (nameB, cout, destB)):
             P = self.model.pslices[name]
@@ -526,6 +524,8 @@ class Engine:
         halves[0][0].pair_buffers = (wf, y2)             # the launch descriptors hold raw pointers: keep the tensors alive
         self._consume(x)
         a = self._conv_args(x, wf, y2.data_ptr(), x.H, x.W, 1, 1, 0, N2, N2, EPI_RAW_STATS, Kp)
+        tiles_m = L.y5m_conv_stats_rows(ctypes.byref(a), dt)
+        self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np2)
         halves[0][0].fwd_args = a
         self._stat_users.append(a)
         self._run_conv(self.fwd, a)

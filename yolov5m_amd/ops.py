@@ -13,8 +13,19 @@ from ._lib import ConvArgs, WgradArgs, EPI_DGRAD, EPI_AFFINE_ACT, EPI_RAW_STATS,
 _DT = {"f32": (F32, torch.float32, 4, 32), "bf16": (BF16, torch.bfloat16, 8, 64)}
 
 
+LAST_KERNEL = None      # which kernel family the most recent y5m_conv launch of this module took (tests assert on it)
+
+
 def _rup(x, m):
     return (x + m - 1) // m * m
+
+
+def _conv(a, dt, what="y5m_conv"):
+    global LAST_KERNEL
+    L = _lib.lib()
+    LAST_KERNEL = ("halo" if L.y5m_conv_is_halo(ctypes.byref(a), dt) else
+                   "pointwise" if L.y5m_conv_is_pointwise(ctypes.byref(a), dt) else "tiled")
+    _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), what)
 
 
 def to_nhwc(x, tdt, cpad=None):
@@ -74,7 +85,7 @@ def conv_forward(x, w, stride, pad, dtype="f32", scale=None, shift=None, act=Fal
             a.res, a.ldres = rn.data_ptr(), Cout
     else:
         a.epi = EPI_DGRAD
-    _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
+    _conv(a, dt)
     torch.cuda.synchronize()
     return from_nhwc(out)
 
@@ -90,8 +101,6 @@ def conv_forward_stats(x, w, stride, pad, dtype="f32"):
     wf, Kp, Np = pack_fwd(w, dtype)
     out = torch.zeros((B, Ho, Wo, Cout), dtype=tdt, device=x.device)
     M = B * Ho * Wo
-    tiles_m = (M + 127) // 128
-    stats = torch.zeros((tiles_m, 2, Np), dtype=torch.float32, device=x.device)
     a = ConvArgs()
     a.zeros = _lib.zero_page(x.device).data_ptr()
     a.inp, a.w, a.out = xn.data_ptr(), wf.data_ptr(), out.data_ptr()
@@ -100,8 +109,10 @@ def conv_forward_stats(x, w, stride, pad, dtype="f32"):
     a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
     a.Cin, a.K, a.Kp, a.N, a.M = Cin, k * k * Cin, Kp, Cout, M
     a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = Ho, Wo, Cout, 1, 1, 0, 0
-    a.Np, a.epi, a.stats = Np, EPI_RAW_STATS, stats.data_ptr()
-    _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
+    a.Np, a.epi = Np, EPI_RAW_STATS
+    stats = torch.zeros((L.y5m_conv_stats_rows(ctypes.byref(a), dt), 2, Np), dtype=torch.float32, device=x.device)
+    a.stats = stats.data_ptr()
+    _conv(a, dt)
     torch.cuda.synchronize()
     s = stats.sum(0)
     return from_nhwc(out), s[0, :Cout], s[1, :Cout]
@@ -171,7 +182,7 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=N
                 keep += [y2n, sc2, sh2]
                 a.bn_y2, a.bn_ldy2, a.bn_scale2, a.bn_shift2 = y2n.data_ptr(), y2.shape[1], sc2.data_ptr(), sh2.data_ptr()
             a.bn_part = part.data_ptr()
-        _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv(dgrad)")
+        _conv(a, dt, "y5m_conv(dgrad)")
         torch.cuda.synchronize()
     if bn is not None:
         ps = part.sum(0)
