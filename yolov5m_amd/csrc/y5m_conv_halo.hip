@@ -39,8 +39,6 @@ struct HaloArgs {
     int tiles_n, total;           // channel tiles per pixel tile, work items
     int Mtot;                     // B*H*W
     int stat_rows;                // rows of the statistics buffer (4 per pixel tile)
-    int dbg;                      // Y5M_HALO_DBG ablation bits (timing experiments only: results are wrong when set)
-    unsigned long long* dbg_out;  // bit 256: per-region cycle counters of (block 0, waves 0 and 7)
 };
 
 template <int NF>
@@ -59,18 +57,163 @@ __device__ __forceinline__ void hl_dma16(const __amdgpu_buffer_rsrc_t rs, unsign
                  :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 pixels of an accumulator fragment), result in every lane: four VALU
+// instructions with DPP operands (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) instead of four
+// ds_bpermute round trips through the LDS pipe
+__device__ __forceinline__ float hl_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// v_bfi_b32: (mask & a) | (~mask & b)
+__device__ __forceinline__ unsigned hl_bfi(unsigned mask, unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
+// The unit loop is ISSUE-bound if written naively: a wave issues about one instruction per 4 cycles, so the ~700
+// scalar / vector instructions per unit of the first version (index arithmetic with divisions, per-fragment address
+// selects, dynamic waits) cost 3x the 48 MFMAs they surround (measured with s_memtime: 4350 cycles per unit, 1100 of
+// them matrix work). This version keeps the per-unit instruction count at ~90 + 48 MFMAs:
+//   * the 9 taps are unrolled statically: weight ring stage = tap % 3 (9 % 3 == 0), tap offsets, wait counts and the
+//     "does this unit carry a patch piece" test are compile-time or one scalar compare;
+//   * everything that depends on the (tile, slab) pair is computed once per pair (9 units) in SGPRs;
+//   * the four pixel fragments of a lane share one swizzle (fragment stride 2048 B does not touch row bits 1-2), so a
+//     tap costs 4 VALU for the base address + 2 per fragment (v_bfe_i32 of the tap-valid bit, v_bfi_b32 select of the
+//     zero row) + 1 per fragment for the second k-step (address ^ 64);
+//   * every wave issues the same number of DMA operations per unit (a piece that does not exist goes, all lanes out of
+//     range, to a 1 KiB dummy region), so the counted vmcnt is an immediate.
+// The 9 statically unrolled tap units of one (tile, slab) pair, expanded inside conv_halo_kernel with NKS = 2 or 1 (k-steps
+// per unit). A unit is 2 * NKS PHASES, each closed by an s_barrier:
+//   R(k): fetch the 4 pixel + NF weight fragments of k-step k (ds_read_b128), wait for the
+//         fragments (lgkmcnt(0): also closes the write-after-read window of the ring stage / patch buffer that the next
+//         DMA overwrites) and, in the unit's last R phase, s_waitcnt vmcnt(N), N = the DMA operations this wave has issued
+//         in this unit so far: everything issued in earlier units has landed, the unit's own prefetches stay in flight
+//         (vmcnt retires loads in order; the epilogue's own loads / stores, issued after them, only make the wait stricter);
+//         the unit's last R phase also computes the NEXT unit's fragment addresses while its reads are in flight;
+//   M(k): the NF * 4 MFMAs of k-step k, back to back, with two LDS-DMA pieces issued between its halves and NOTHING else:
+//         20 address VALU instructions interleaved with the 24 MFMAs made the phase 690 instead of 380 cycles (s_memtime).
+// DMA pieces of a unit, in issue order: the patch piece of the NEXT pair and weight piece 0 of unit g+2 (M0), weight pieces
+// 1, 2 (M1): an LDS-DMA issue costs the wave ~100-180 cycles next to ds_reads in flight, but next to nothing between MFMAs. A piece that does not exist goes, all lanes out of range, to the dummy region, so every wave issues the same
+// number of operations per unit.
+// Waves 4-7 run ONE PHASE BEHIND waves 0-3 (an extra barrier before the loop, see the kernel): wave w and w + 4 share a
+// SIMD, so one of them is always in an M phase while the other is in an R phase -- the matrix pipe sees back-to-back
+// MFMAs and the LDS sees the reads of four waves at a time. The first R phase of a tile runs the previous tile's epilogue.
+#ifdef HL_TIMING
 __device__ __forceinline__ unsigned long long hl_clock() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     return t;
 }
-#define HL_T(i) do { if (G.dbg & 256) { const unsigned long long now_ = hl_clock(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
+#define HL_PHASE_END() \
+                __builtin_amdgcn_sched_barrier(0); \
+                { const unsigned long long n_ = hl_clock(); tacc[2 * (tph & 3)] += n_ - tlast; tlast = n_; } \
+                __builtin_amdgcn_s_barrier(); \
+                { const unsigned long long n_ = hl_clock(); tacc[2 * (tph & 3) + 1] += n_ - tlast; tlast = n_; ++tph; } \
+                __builtin_amdgcn_sched_barrier(0);
+#else
+#define HL_PHASE_END() \
+                __builtin_amdgcn_sched_barrier(0); \
+                __builtin_amdgcn_s_barrier(); \
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#define HL_MFMAS(A0, A1) \
+_Pragma("unroll") \
+                for (int a = A0; a < A1; ++a) \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; ++b) \
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
+                            __builtin_bit_cast(bf16x8_t, wb[a]), __builtin_bit_cast(bf16x8_t, xa[b]), acc[a][b], 0, 0, 0);
+#ifdef HL_X_EMPTYR
+#define HL_NEXT_ADDR()
+#define HL_PVOFF(a, b, c, d) OOB
+#else
+#define HL_PVOFF(a, b, c, d) patch_piece_voff(a, b, c, d)
+#define HL_NEXT_ADDR() \
+                if (t < 8) { \
+                    tap_addr(pbo, t + 1); \
+                } else { \
+                    if (ns == 0 && nvalid) setup_masks(nm0); \
+                    tap_addr(npbo, 0); \
+                }
+#endif
+#ifdef HL_X_NOVM
+#define HL_WAIT_R1() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define HL_WAIT_R1() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+#endif
+#if defined(HL_X_NOREAD) || defined(HL_X_EMPTYR)
+#define HL_LD(dst, adr) asm volatile("" : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w) : "v"(adr));
+#else
+#define HL_LD(dst, adr) dst = *reinterpret_cast<const uint4*>(smem + (adr));
+#endif
+#ifdef HL_X_NOPRIO
+#define HL_PRIO(x)
+#else
+#define HL_PRIO(x) __builtin_amdgcn_s_setprio(x);
+#endif
+#define HL_UNITS(NKS) \
+_Pragma("unroll") \
+            for (int t = 0; t < 9; ++t) { \
+                HL_PRIO(2) \
+                if (t == 0 && s == 0) { \
+                    if (pending) epilogue(); \
+_Pragma("unroll") \
+                    for (int a = 0; a < NF; ++a) \
+_Pragma("unroll") \
+                        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; \
+                    etile = tile_m; \
+                    em0 = m0; \
+                    en0 = n0; \
+                    pending = true; \
+                } \
+                const unsigned wbase = wl + (unsigned)((t % 3) * WB); \
+                const unsigned wsrc = t + 2 < 9 ? wso : nwso; \
+                const int wtap = t + 2 < 9 ? t + 2 : t + 2 - 9; \
+_Pragma("unroll") \
+                for (int b = 0; b < 4; ++b) { HL_LD(xa[b], a0[b]) } \
+_Pragma("unroll") \
+                for (int a = 0; a < NF; ++a) { HL_LD(wb[a], wbase + (unsigned)(a * 2048)) } \
+                const unsigned pvoff = HL_PVOFF(npix0, ncbo, nchan_ok, t * 8 + wid); \
+                if (NKS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                else { \
+                    HL_NEXT_ADDR() \
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                } \
+                HL_PRIO(0) \
+                HL_PHASE_END() \
+                HL_MFMAS(0, NF / 2) \
+                issue_patch_piece(pvoff, t * 8 + wid, npbo); \
+                if (NKS == 2) issue_weights(wsrc, wtap, 0, 1); \
+                else issue_weights(wsrc, wtap, 0, NWP); \
+                HL_MFMAS(NF / 2, NF) \
+                HL_PHASE_END() \
+                if (NKS == 2) { \
+                    HL_PRIO(2) \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; ++b) { HL_LD(xa[b], a0[b] ^ 64u) } \
+_Pragma("unroll") \
+                    for (int a = 0; a < NF; ++a) { HL_LD(wb[a], (wbase ^ 64u) + (unsigned)(a * 2048)) } \
+                    HL_NEXT_ADDR() \
+                    HL_WAIT_R1() \
+                    HL_PRIO(0) \
+                    HL_PHASE_END() \
+                    HL_MFMAS(0, NF / 2) \
+                    issue_weights(wsrc, wtap, 1, NWP); \
+                    HL_MFMAS(NF / 2, NF) \
+                    HL_PHASE_END() \
+                } \
+            }
 
 template <int NF, int EPI>
 __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams P, const HaloArgs G) {
     constexpr int BN = 2 * NF * 16;                       // channels per tile (2 channel groups of waves)
     constexpr int WB = BN * 128;                          // bytes of one weight stage
-    constexpr int NWP = (BN / 8 + 7) / 8;                 // weight DMA pieces per wave and unit (3 | 2, the second partial)
+    constexpr int NWP = (BN / 8 + 7) / 8;                 // weight DMA pieces per wave and unit (3 | 2)
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
 
@@ -81,8 +224,8 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
     const int W = P.Win, H = P.Hin;
     const int PB = G.PR8 * 128;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
-    // LDS map: [zero row 128][patch 0][patch 1][weight stage 0..2]
-    const unsigned Z_OFF = 0, P_OFF = 128, W_OFF = 128 + 2 * PB;
+    // LDS map: [patch 0][patch 1][weight stage 0..2][zero row 128][dummy 1024]
+    const unsigned P_OFF = 0, W_OFF = 2 * PB, Z_OFF = W_OFF + HL_NS * WB, D_OFF = Z_OFF + 128;
 
     if (tid < 8) *reinterpret_cast<uint4*>(smem + Z_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
@@ -99,61 +242,32 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
         const int r = (wid + 8 * j) * 8 + dr;
         const int rw = r / (NF * 16), rl = r - rw * (NF * 16);
         const int rp = rw * (NF * 16) + hl_pch<NF>(rl >> 4, rl & 15);
-        wvoff[j] = (unsigned)((rp * P.Kp + ((dq ^ (r & 6)) << 3)) * 2);
+        // (a piece behind the tile's BN rows only exists for BN = 96, waves 4-7, j = 1: it goes to the dummy region)
+        wvoff[j] = wid + 8 * j < BN / 8 ? (unsigned)((rp * P.Kp + ((dq ^ (r & 6)) << 3)) * 2) : OOB;
     }
     const unsigned ldb = (unsigned)(P.ldin * 2);
+    const int pch = dq ^ (dr & 6);                         // logical chunk this lane fetches of a patch row (piece rows start at a multiple of 8)
+    const unsigned pl_off = (unsigned)(pch << 4);
+    const bool pl_last_ok = (G.S - 1) * 64 + pch * 8 < P.Cin;      // upper half of a 32-channel last slab reads as zeros
+    const unsigned wdst = lds0 + (unsigned)(wid * 1024);   // + stage + j*8192: this wave's weight pieces
 
     // ---- fragment read addresses -----------------------------------------------------------------------------
-    // weights (MFMA A operand): row nl = wn*NF*16 + a*16 + frow; (nl >> 1) & 7 does not depend on a
-    const unsigned wl = (unsigned)((wn * NF * 16 + frow) * 128 + ((fq ^ (frow & 6)) << 4));
+    // weights (MFMA A operand): row nl = wn*NF*16 + a*16 + frow; nl & 6 == frow & 6
+    const unsigned wl = W_OFF + (unsigned)((wn * NF * 16 + frow) * 128 + ((fq ^ (frow & 6)) << 4));
     // pixels (MFMA B operand): patch row of tile pixel ml at tap offset 0 is ml + W + 1
-    const unsigned prow = (unsigned)((wm * 64 + frow + W + 1) * 128);
+    const unsigned prow = P_OFF + (unsigned)((wm * 64 + frow + W + 1) * 128);
+    const unsigned fq16 = (unsigned)fq << 4;
+    const unsigned zadr = Z_OFF + fq16;
+
+    // tap offsets in patch rows * 128 (SGPRs)
+    int tapd[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tapd[k] = ((P.dh0 + (k / 3) * P.dhs) * W + (P.dw0 + (k % 3) * P.dws)) * 128;
+    const unsigned C2 = (unsigned)(P.Cin * 2);
 
     // ---- work items --------------------------------------------------------------------------------------------
     const int nblk = gridDim.x;
-    const int lid0 = hl_logical_id(blockIdx.x, nblk);
-    // current unit
-    int it = lid0, s = 0, t = 0;
-    // weight prefetch cursor (two units ahead)
-    int pit = lid0, ps = 0, pt = 0;
-    unsigned wst0 = W_OFF, wst1 = W_OFF + WB, wst2 = W_OFF + 2 * WB;      // stage of unit g, g+1, g+2
-    int pcur = 0;                                                        // patch buffer of the current slab
-
-    auto issue_weights = [&](int xit, int xs, int xt, unsigned stage) __attribute__((always_inline)) {
-        const int n0 = (xit % G.tiles_n) * BN;
-        const unsigned soff = (unsigned)((n0 * P.Kp + xt * P.Cin + xs * 64) * 2);
-#pragma unroll
-        for (int j = 0; j < NWP; ++j) {
-            if (wid + 8 * j < BN / 8) hl_dma16(rs_w, wvoff[j], soff, lds0 + stage + (unsigned)((wid + 8 * j) * 1024));
-        }
-    };
-    auto issue_patch_piece = [&](int xit, int xs, int pc, int buf) __attribute__((always_inline)) {
-        if (pc < G.npieces) {
-            const int m0 = (xit / G.tiles_n) * HL_TP;
-            const int r = pc * 8 + dr;
-            const int pix = m0 - (W + 1) + r;
-            const int ch = dq ^ (r & 6);                         // logical 16-byte chunk (8 channels) of this LDS position
-            const unsigned off = __umul24((unsigned)pix, ldb) + (unsigned)(xs * 128 + (ch << 4));
-            // rows outside the tensor and the channels behind Cin (upper half of a 32-channel last slab) read as zeros
-            const bool ok = (unsigned)pix < (unsigned)G.Mtot && xs * 64 + ch * 8 < P.Cin;
-            hl_dma16(rs_x, ok ? off : OOB, 0u, lds0 + P_OFF + (unsigned)(buf * PB + pc * 1024));
-        }
-    };
-    auto advance = [&](int& xit, int& xs, int& xt) __attribute__((always_inline)) {
-        if (++xt == 9) {
-            xt = 0;
-            if (++xs == G.S) { xs = 0; xit += nblk; }
-        }
-    };
-
-    // ---- prologue: first patch, weights of units 0 and 1 --------------------------------------------------------
-    for (int i = 0; i < G.NPU; ++i) issue_patch_piece(it, 0, i * 8 + wid, 0);
-    issue_weights(pit, ps, pt, wst0);
-    advance(pit, ps, pt);
-    if (pit < G.total) issue_weights(pit, ps, pt, wst1);
-    advance(pit, ps, pt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    int it = hl_logical_id(blockIdx.x, nblk);
 
     f32x4 acc[NF][4];
     unsigned vmask[4] = {0u, 0u, 0u, 0u};                  // 9 tap-valid bits per pixel fragment of this lane
@@ -173,10 +287,7 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float v = acc[a][b][r]; sv[r] += v; ss[r] += v * v; }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) { sv[r] += __shfl_xor(sv[r], o, 64); ss[r] += __shfl_xor(ss[r], o, 64); }
-                    }
+                    for (int r = 0; r < 4; ++r) { sv[r] = hl_row_sum(sv[r]); ss[r] = hl_row_sum(ss[r]); }
                     if (frow == 0) {
                         const int n = nb + hl_pch<NF>(a, fq * 4);
                         float* row = P.stats + ((size_t)(etile * 4 + wm) * 2) * P.Np + n;
@@ -239,9 +350,7 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
         }
     };
 
-    // ---- fragment addressing ------------------------------------------------------------------------------------
-    auto setup_masks = [&](int xit) __attribute__((always_inline)) {
-        const int m0 = (xit / G.tiles_n) * HL_TP;
+    auto setup_masks = [&](int m0) __attribute__((always_inline)) {
         const float rcpW = 1.0f / (float)W, rcpH = 1.0f / (float)H;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -259,146 +368,104 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
             vmask[b] = m < G.Mtot ? mk : 0u;
         }
     };
-    unsigned a0[4];                                        // LDS byte address of this lane's k-step-0 chunk per pixel fragment
-    auto tap_addr = [&](int buf, int xt) __attribute__((always_inline)) {
-        const int ta = xt / 3, tb = xt - ta * 3;
-        const int d = (P.dh0 + ta * P.dhs) * W + (P.dw0 + tb * P.dws);
+    // addresses of this lane's k-step-0 chunks of the 4 pixel fragments at tap k of the patch buffer at byte offset pbo
+    unsigned a0[4];
+    auto tap_addr = [&](unsigned pbo, int k) __attribute__((always_inline)) {
+        const unsigned rowb = prow + (pbo + (unsigned)tapd[k]);
+        const unsigned adr = rowb + (fq16 ^ ((rowb >> 3) & 0x60u));          // chunk ^= row & 6; same for all 4 fragments
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const unsigned rowb = prow + (unsigned)(b * 2048) + (unsigned)(d * 128);     // row * 128 inside the patch
-            const unsigned sw = (rowb >> 3) & 0x60u;                                     // (row & 6) << 4
-            const unsigned adr = P_OFF + (unsigned)(buf * PB) + rowb + (((unsigned)fq << 4) ^ sw);
-            a0[b] = ((vmask[b] >> xt) & 1u) ? adr : (Z_OFF + ((unsigned)fq << 4));
+            const unsigned ok = (unsigned)__builtin_amdgcn_sbfe((int)vmask[b], k, 1);     // 0 or 0xffffffff
+            a0[b] = hl_bfi(ok, adr + (unsigned)(b * 2048), zadr);
         }
     };
-    auto mfma_step = [&](const uint4 (&xa)[4], const uint4 (&wb)[NF]) __attribute__((always_inline)) {
+    // weights of (channel-tile offset wso = (n0*Kp + slab*64)*2, tap k) into ring stage k % 3
+    auto issue_weights = [&](unsigned wso, int k, int j0, int j1) __attribute__((always_inline)) {
+#ifdef HL_X_NOWDMA
+        return;
+#endif
+        const unsigned soff = wso + (unsigned)k * C2;
+        const unsigned dst = wdst + W_OFF + (unsigned)((k % 3) * WB);
 #pragma unroll
-        for (int a = 0; a < NF; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, wb[a]), __builtin_bit_cast(bf16x8_t, xa[b]), acc[a][b], 0, 0, 0);
+        for (int j = 0; j < NWP; ++j)
+            if (j >= j0 && j < j1)
+                hl_dma16(rs_w, wvoff[j], soff, wid + 8 * j < BN / 8 ? dst + (unsigned)(j * 8192) : lds0 + D_OFF);
+    };
+    // piece pc of the patch whose first row is pixel pix0 (may be negative), channel byte offset cbo, into buffer pbo
+    auto patch_piece_voff = [&](int pix0, unsigned cbo, bool chan_ok, int pc) __attribute__((always_inline)) {
+        const int pix = pix0 + pc * 8 + dr;
+        const unsigned off = __umul24((unsigned)pix, ldb) + (cbo + pl_off);
+        const bool ok = (unsigned)pix < (unsigned)G.Mtot && chan_ok && pc < G.npieces;
+        return ok ? off : OOB;
+    };
+    auto issue_patch_piece = [&](unsigned voff, int pc, unsigned pbo) __attribute__((always_inline)) {
+#ifdef HL_X_NOPDMA
+        return;
+#endif
+        hl_dma16(rs_x, voff, 0u, pc < G.npieces ? lds0 + P_OFF + pbo + (unsigned)(pc * 1024) : lds0 + D_OFF);
     };
 
-    // pixel fragments of the first unit (the patch is complete and does not change during a slab, so the NEXT unit's
-    // pixel fragments are always fetched under the current unit's MFMAs; only the weight fragments of k-step 0 are read
-    // after the unit's barrier)
-    uint4 xa0[4], xa1[4], wb0[NF], wb1[NF];
-    setup_masks(it);
-    tap_addr(0, 0);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) xa0[b] = *reinterpret_cast<const uint4*>(smem + a0[b]);
+    // ---- prologue: first patch, weights of units 0 and 1 --------------------------------------------------------
+    {
+        const int m0 = (it / G.tiles_n) * HL_TP;
+        const unsigned wso = (unsigned)(((it % G.tiles_n) * BN * P.Kp) * 2);
+        for (int i = 0; i < G.NPU; ++i)
+            issue_patch_piece(patch_piece_voff(m0 - (W + 1), 0u, G.S > 1 || pl_last_ok, i * 8 + wid), i * 8 + wid, 0u);
+        issue_weights(wso, 0, 0, NWP);
+        issue_weights(wso, 1, 0, NWP);
+        setup_masks(m0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (G.dbg & 256) ? hl_clock() : 0ull;
-    // ---- unit loop ---------------------------------------------------------------------------------------------
+    uint4 xa[4], wb[NF];
+#ifdef HL_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = hl_clock();
+    int tph = 0;
+#endif
+    tap_addr(0u, 0);
+    // waves 4-7 run one phase behind waves 0-3 (HL_UNITS); every wave executes the same number of barriers in total
+    if (wid >= 4) __builtin_amdgcn_s_barrier();
+
+    // ---- (tile, slab) pair loop, 9 statically unrolled tap units each -------------------------------------------
+    int s = 0;
+    unsigned pbo = 0u;                                     // byte offset of the current slab's patch buffer
     while (it < G.total) {
+        // per-pair scalars: this pair and the next one (same tile next slab, or the next tile's first slab)
+        const int tile_m = it / G.tiles_n;
+        const int m0 = tile_m * HL_TP, n0 = (it - tile_m * G.tiles_n) * BN;
+        const unsigned wso = (unsigned)((n0 * P.Kp + s * 64) * 2);
         const int nks = (P.Cin - s * 64) >= 64 ? 2 : 1;
-        const unsigned wbase = wst0 + wl;
-        // (a) this unit's remaining fragments
-        if (!(G.dbg & 8)) {
-#pragma unroll
-        for (int a = 0; a < NF; ++a) wb0[a] = *reinterpret_cast<const uint4*>(smem + (wbase + (unsigned)(a * 2048)));
-        if (nks == 2) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) xa1[b] = *reinterpret_cast<const uint4*>(smem + (a0[b] ^ 64u));
-#pragma unroll
-            for (int a = 0; a < NF; ++a) wb1[a] = *reinterpret_cast<const uint4*>(smem + ((wbase ^ 64u) + (unsigned)(a * 2048)));
+        int ns = s + 1, nit = it;
+        if (ns == G.S) { ns = 0; nit += nblk; }
+        const bool nvalid = nit < G.total;
+        const int ntile_m = nit / G.tiles_n;
+        const int nm0 = ntile_m * HL_TP, nn0 = (nit - ntile_m * G.tiles_n) * BN;
+        const unsigned nwso = nvalid ? (unsigned)((nn0 * P.Kp + ns * 64) * 2) : wso;       // (no next pair: any valid address)
+        const int npix0 = nvalid ? nm0 - (W + 1) : (1 << 30);                              // (no next pair: every lane out of range)
+        const unsigned ncbo = (unsigned)(ns * 128);
+        const bool nchan_ok = ns < G.S - 1 || pl_last_ok;
+        const unsigned npbo = pbo ^ (unsigned)PB;          // patch buffers at 0 and PB
+        // the 9 tap units of this pair; NKS (k-steps per unit: 2, or 1 for a 32-channel last slab) is a compile-time
+        // constant of the unrolled sequence, so that no fragment read sits in a conditional block (the compiler's
+        // counted lgkmcnt before the first MFMA otherwise has to assume the shorter path and waits for the k-step-1 reads)
+        // the 9 tap units of this pair (HL_UNITS, defined above the kernel); NKS (k-steps per unit: 2, or 1 for a 32-channel
+        // last slab) is a literal in each expansion, so that no fragment read sits in a conditional block
+        if constexpr (NF == 3) {
+            if (nks == 2) { HL_UNITS(2) } else { HL_UNITS(1) }
+        } else {
+            HL_UNITS(2)                                    // (the 192-channel tile requires Cin % 64 == 0: halo_geom)
         }
-        }
-        // (b) prefetch: one patch piece of the next (tile, slab) pair, weights of unit g+2
-        int nissued = 0;                                   // VMEM operations this wave issues in this unit (wave-uniform)
-        {
-            int nit = it, ns = s + 1;
-            if (ns == G.S) { ns = 0; nit += nblk; }
-            if (t < G.NPU && nit < G.total && t * 8 + wid < G.npieces && !(G.dbg & 2)) {
-                issue_patch_piece(nit, ns, t * 8 + wid, pcur ^ 1);
-                nissued = 1;
-            }
-        }
-        if (pit < G.total && !(G.dbg & 1)) {
-            issue_weights(pit, ps, pt, wst2);
-            nissued += (NWP == 3) ? 3 : (wid < 4 ? 2 : 1);
-        }
-        advance(pit, ps, pt);
-        HL_T(0);
-        // (c) first unit of a tile: retire the previous tile
-        if (s == 0 && t == 0) {
-            if (pending) epilogue();
-#pragma unroll
-            for (int a = 0; a < NF; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            etile = it / G.tiles_n;
-            em0 = etile * HL_TP;
-            en0 = (it % G.tiles_n) * BN;
-            pending = true;
-        }
-        HL_T(1);
-        // (d) k-step 0
-        if (!(G.dbg & 4)) mfma_step(xa0, wb0);
-        else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(xa0[b].x), "v"(xa0[b].y), "v"(xa0[b].z), "v"(xa0[b].w));
-#pragma unroll
-            for (int a = 0; a < NF; ++a) asm volatile("" :: "v"(wb0[a].x), "v"(wb0[a].y), "v"(wb0[a].z), "v"(wb0[a].w));
-        }
-        HL_T(2);
-        // (e) pixel fragments of the NEXT unit (its patch buffer is complete: see the wait in (g))
-        {
-            int uit = it, us = s, ut = t + 1, ubuf = pcur;
-            if (ut == 9) {
-                ut = 0;
-                ubuf ^= 1;
-                if (++us == G.S) { us = 0; uit += nblk; }
-            }
-            if (uit < G.total) {
-                if (us == 0 && ut == 0) setup_masks(uit);
-                tap_addr(ubuf, ut);
-                if (!(G.dbg & 8)) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) xa0[b] = *reinterpret_cast<const uint4*>(smem + a0[b]);
-                }
-            }
-        }
-        HL_T(3);
-        // (f) k-step 1
-        if (nks == 2) {
-            if (!(G.dbg & 4)) mfma_step(xa1, wb1);
-            else {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(xa1[b].x), "v"(xa1[b].y), "v"(xa1[b].z), "v"(xa1[b].w));
-#pragma unroll
-                for (int a = 0; a < NF; ++a) asm volatile("" :: "v"(wb1[a].x), "v"(wb1[a].y), "v"(wb1[a].z), "v"(wb1[a].w));
-            }
-        }
-        HL_T(4);
-        // (g) everything issued before this unit has landed; the unit's own prefetches stay in flight
-        //     (vmcnt retires loads in order: "at most nissued outstanding" = every older DMA has landed; the epilogue's
-        //     own loads / stores, issued after them, only make the wait stricter). lgkmcnt(0): this wave's fragment
-        //     reads of the stage that the next unit's DMA overwrites have returned before anyone passes the barrier.
-        switch (nissued) {
-        case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-        }
-        HL_T(5);
-        if (!(G.dbg & 16)) __builtin_amdgcn_s_barrier();
-        HL_T(6);
-        // (h) next unit
-        { const unsigned x = wst0; wst0 = wst1; wst1 = wst2; wst2 = x; }
-        if (++t == 9) {
-            t = 0;
-            pcur ^= 1;
-            if (++s == G.S) { s = 0; it += nblk; }
-        }
+        pbo = npbo;
+        s = ns;
+        it = nit;
     }
+    if (wid < 4) __builtin_amdgcn_s_barrier();
     if (pending) epilogue();
-    if ((G.dbg & 256) && blockIdx.x == 0 && (wid == 0 || wid == 7) && lane == 0) {
-        HL_T(7);
-        for (int i = 0; i < 8; ++i) G.dbg_out[(wid ? 8 : 0) + i] = tacc[i];
-    }
+#ifdef HL_TIMING
+    if (blockIdx.x == 0 && (wid == 0 || wid == 4) && lane == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(const_cast<void*>(P.zeros))[32 + (wid ? 8 : 0) + i] = tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -417,7 +484,7 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     if (P.bn_part) return false;
     if (P.Cin < 64 || P.Cin % 32 != 0 || P.ldin % 8 != 0) return false;
     if (P.N % 96 != 0) return false;
-    BN = P.N % 192 == 0 ? 192 : 96;
+    BN = (P.N % 192 == 0 && P.Cin % 64 == 0) ? 192 : 96;
     if (P.Np < (P.N + BN - 1) / BN * BN) return false;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return false;      // 16-byte output pieces
     if (P.res && P.ldres % 4 != 0) return false;
@@ -430,8 +497,8 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     G.PR8 = (PR + 7) / 8 * 8;
     G.npieces = G.PR8 / 8;
     G.NPU = (G.npieces + 7) / 8;
-    if (G.NPU > 8) return false;
-    const size_t lds = 128 + 2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128;
+    if (G.NPU > 8) return false;           // one piece per wave and unit, units 0..7 (a piece issued in unit 8 would not be waited for before the slab switch)
+    const size_t lds = 2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128 + 128 + 1024;
     if (lds > 160 * 1024) return false;
     G.S = S;
     G.tiles_n = (P.N + BN - 1) / BN;
@@ -439,7 +506,6 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     G.total = tiles_m * G.tiles_n;
     G.Mtot = (int)Mtot;
     G.stat_rows = tiles_m * 4;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("Y5M_HALO_DBG"); dbg = e ? atoi(e) : 0; } G.dbg = dbg; G.dbg_out = nullptr; }
     return true;
 }
 
@@ -466,7 +532,7 @@ extern "C" int y5m_conv_is_halo(const y5m_conv_args* args, int dtype) {
 template <int NF, int EPI>
 static int launch_halo(const ConvParams& P, const HaloArgs& G, hipStream_t st) {
     constexpr int BN = 2 * NF * 16;
-    const size_t lds = 128 + 2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128;
+    const size_t lds = 2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128 + 128 + 1024;
     auto kern = conv_halo_kernel<NF, EPI>;
     static bool attr = false;
     if (!attr) {
@@ -480,26 +546,6 @@ static int launch_halo(const ConvParams& P, const HaloArgs& G, hipStream_t st) {
         if (g_halo_cus <= 0) g_halo_cus = 256;
     }
     const int grid = G.total < g_halo_cus ? G.total : g_halo_cus;
-    if (G.dbg & 256) {
-        static unsigned long long* d = nullptr;
-        if (!d) (void)hipMalloc(&d, 16 * sizeof(unsigned long long));
-        HaloArgs G2 = G;
-        G2.dbg_out = d;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(HL_THREADS), lds, st, P, G2);
-        (void)hipDeviceSynchronize();
-        unsigned long long h[16];
-        (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-        static int printed = 0;
-        if (printed++ % 50 == 10) {
-            const char* nm[8] = {"reads+dma", "epi/zero", "mfma k0", "pre-read", "mfma k1", "wait", "barrier", "tail"};
-            for (int w = 0; w < 2; ++w) {
-                fprintf(stderr, "halo dbg wave %d:", w ? 7 : 0);
-                for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu", nm[i], h[w * 8 + i]);
-                fprintf(stderr, "\n");
-            }
-        }
-        return Y5M_OK;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(HL_THREADS), lds, st, P, G);
     Y5M_CHECK_LAUNCH("conv_halo_kernel");
     return Y5M_OK;
