@@ -97,15 +97,37 @@ HALO_CASES = [
 ]
 
 
+def _halo_expected(Cin, N):
+    """the library's dispatch rule (y5m_conv_halo.hip halo_geom): 192-channel tiles by default, the 96-channel tile only
+    with Y5M_CONV_HALO=2 (test_halo_96_channel_tile_subprocess runs this file's halo tests that way)"""
+    import os
+    lvl = int(os.environ.get("Y5M_CONV_HALO", "1"))
+    wide = N % 192 == 0 and Cin % 64 == 0
+    return "halo" if (lvl >= 1 and wide) or (lvl >= 2 and N % 96 == 0) else None
+
+
+def test_halo_96_channel_tile_subprocess():
+    """the 96-channel tile of the halo kernel is off by default (slower than the tiled kernel on N = 96); its code path --
+    32-channel last slab, two weight pieces per wave with the dummy-region redirect -- is checked in a child process"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_CONV_HALO") == "2":
+        pytest.skip("already the child")
+    env = dict(os.environ, Y5M_CONV_HALO="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "halo_forward or halo_dgrad"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_halo_forward_stats_and_epilogue(case):
     from yolov5m_amd import ops
     B, Cin, H, W, Cout = case
+    want = _halo_expected(Cin, Cout)
     x = _q(_rand((B, Cin, H, W), 61), "bf16")
     w = _q(_rand((Cout, Cin, 3, 3), 62, -0.1, 0.1), "bf16")
     ref = F.conv2d(x, w, None, 1, 1)
     got, s1, s2 = ops.conv_forward_stats(x.to(DEV), w.to(DEV), 1, 1, "bf16")
-    assert ops.LAST_KERNEL == "halo"
+    assert want is None or ops.LAST_KERNEL == want
     assert _relerr(got.cpu(), ref) < TOL["bf16"], _relerr(got.cpu(), ref)
     np.testing.assert_allclose(s1.cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.02 * float(ref.abs().max()) * 8)
     np.testing.assert_allclose(s2.cpu().numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.05)
@@ -114,7 +136,7 @@ def test_halo_forward_stats_and_epilogue(case):
     ref2 = F.silu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res
     got2 = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 1, "bf16", scale=sc.to(DEV), shift=sh.to(DEV), act=True,
                             res=res.to(DEV)).cpu()
-    assert ops.LAST_KERNEL == "halo"
+    assert want is None or ops.LAST_KERNEL == want
     assert _relerr(got2, ref2) < TOL["bf16"]
 
 
@@ -133,10 +155,9 @@ def test_halo_dgrad(case, mode):
         extra = _q(_rand((B, Cin, H, W), 68), "bf16")
         ref = ref + extra
         kw = {"init": extra.to(DEV)} if mode == "init" else {"src": extra.to(DEV)}
-    if Cin % 96 != 0:
-        pytest.skip("data gradient has N = Cin output channels: not a halo shape")
+    want = _halo_expected(Cout, Cin)               # the data gradient has Cout input and Cin output channels
     got = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, 1, "bf16", **kw).cpu()
-    assert ops.LAST_KERNEL == "halo"
+    assert want is None or ops.LAST_KERNEL == want
     assert _relerr(got, ref) < TOL["bf16"], _relerr(got, ref)
 
 

@@ -7,25 +7,31 @@
 //     are the raster run [m0 - W - 1, m0 + 256 + W + 1): one "patch" of 258 + 2W rows x 64 channels (128 B rows).
 //     It is staged ONCE per 64-channel slab and every tap reads it at a row offset dy*W + dx; taps that fall outside
 //     the image (or rows behind the tensor) are redirected per lane to a 128-byte zero row;
-//   * the weights of one (slab, tap) unit (BN rows x 128 B) stream through a 3-stage LDS ring;
-//   * BOTH operands arrive by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction; semantics probed on
-//     hardware by tools/probe_lds_dma.hip: destination = M0 + lane*16, out-of-range lanes write zeros). The LDS image
-//     is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and again to the fragment read
-//     address. The swizzle is chunk ^= row & 6 (not the tiled kernel's (row>>1)&7): a tap shifts the 16 rows of a
-//     fragment by dy*W+dx, and (row>>1)&7 is 2-way conflicted for 3 of 4 row alignments, row&6 for none (bank model
-//     of the ds_read_b128 lane groups, MI355X_MICROARCH LDS table, searched exhaustively over linear swizzles);
-//   * ONE s_barrier and ONE counted s_waitcnt vmcnt(N) per unit (48 MFMAs per wave at BN = 192): the weights of unit
-//     g+2 and a piece of the NEXT slab's (or next tile's) patch are issued at the top of unit g and are only waited
-//     for at the end of unit g+1 -- nothing in the loop drains the VMEM queue;
+//   * the weights of one (slab, tap) unit (BN rows x 128 B, L2-resident) stream through a 3-stage LDS ring;
+//   * operands travel global -> VGPR (buffer loads with hardware zero fill of out-of-range rows, issued between the
+//     MFMAs of one unit) -> LDS (ds_write_b128 one unit later): two units of latency tolerance, waits counted by the
+//     compiler. The LDS image of a 1 KiB piece is lane-linear (piece base + lane*16) and the bank swizzle sits on the
+//     per-lane SOURCE address and again on the fragment read address -- the layout an LDS-DMA produces (probed on
+//     hardware, tools/probe_lds_dma.hip), which the prologue still uses. The swizzle is chunk ^= row & 6 (not the tiled
+//     kernel's (row>>1)&7): a tap shifts the 16 rows of a fragment by dy*W+dx, and (row>>1)&7 is 2-way conflicted for 3
+//     of 4 row alignments, row&6 for none (bank model of the ds_read_b128 lane groups, MI355X_MICROARCH LDS table,
+//     searched over all linear swizzles; PMC: SQ_LDS_BANK_CONFLICT = 5 % of SQ_LDS_IDX_ACTIVE);
 //   * workgroups are persistent (one per CU, 8 waves = 4 pixel groups x 2 channel groups, wave tile 64 x {48,96}):
-//     the next tile's first patch and weights are in flight while the current tile finishes, and the epilogue of a
-//     tile is issued at the top of the next tile's first unit so its stores drain under that unit's MFMAs.
-// Traffic per tile (192 -> 192 channels, W = 40): 130 KB of patch + 663 KB of (L2-resident) weights for 170 MFLOP;
-// the tiled kernel staged 1.15 MB of activations + 0.66 MB of weights for the same work, all through ds_write.
+//     the next tile's first patch and weights are in flight while the current tile finishes;
+//   * waves 0-3 and 4-7 (the two waves of each SIMD) run one PHASE apart: while one group issues the 48 MFMAs of a
+//     unit, the other fetches its fragments, stores the staged operands and computes addresses (see HL_UNITS).
+// Traffic per tile (192 -> 192 channels, W = 40): 130 KB of patch + 663 KB of weights for 170 MFLOP; the tiled kernel
+// staged 1.15 MB of activations + 0.66 MB of weights for the same work.
+// Measured (B = 80 x 40x40 x 192 -> 192, two full rounds of tiles): 1.0-1.1 PFLOP/s against 0.67-0.77 for the tiled
+// kernel. What was tried on the way, with numbers, is in DESIGN.md section 4a (LDS-DMA for everything: each
+// buffer_load ... lds stalled its wave 100-300 cycles inside the MFMA stream; four 24-MFMA phases per unit instead of
+// two 48-MFMA ones; s_setprio for the fetching group; all within +-3 % of this version).
 #include "y5m_conv.h"
 
 #include <stdlib.h>
 #include <string.h>
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define HL_THREADS 512
 #define HL_TP 256                 // pixels per tile
@@ -69,40 +75,33 @@ __device__ __forceinline__ float hl_row_sum(float v) {
 }
 
 // v_bfi_b32: (mask & a) | (~mask & b)
-__device__ __forceinline__ unsigned hl_bfi(unsigned mask, unsigned a, unsigned b) {
-    unsigned r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
-    return r;
-}
+__device__ __forceinline__ unsigned hl_bfi(unsigned mask, unsigned a, unsigned b) { return (mask & a) | (~mask & b); }
 
 // The unit loop is ISSUE-bound if written naively: a wave issues about one instruction per 4 cycles, so the ~700
 // scalar / vector instructions per unit of the first version (index arithmetic with divisions, per-fragment address
 // selects, dynamic waits) cost 3x the 48 MFMAs they surround (measured with s_memtime: 4350 cycles per unit, 1100 of
-// them matrix work). This version keeps the per-unit instruction count at ~90 + 48 MFMAs:
-//   * the 9 taps are unrolled statically: weight ring stage = tap % 3 (9 % 3 == 0), tap offsets, wait counts and the
-//     "does this unit carry a patch piece" test are compile-time or one scalar compare;
+// them matrix work). This version keeps a unit at ~40 VALU + ~25 SALU + 24 LDS + 4 VMEM instructions + 48 MFMAs:
+//   * the 9 taps are unrolled statically (HL_UNITS): weight ring stage = tap % 3 (9 % 3 == 0), tap offsets and LDS
+//     store offsets are immediates;
 //   * everything that depends on the (tile, slab) pair is computed once per pair (9 units) in SGPRs;
 //   * the four pixel fragments of a lane share one swizzle (fragment stride 2048 B does not touch row bits 1-2), so a
-//     tap costs 4 VALU for the base address + 2 per fragment (v_bfe_i32 of the tap-valid bit, v_bfi_b32 select of the
-//     zero row) + 1 per fragment for the second k-step (address ^ 64);
-//   * every wave issues the same number of DMA operations per unit (a piece that does not exist goes, all lanes out of
-//     range, to a 1 KiB dummy region), so the counted vmcnt is an immediate.
-// The 9 statically unrolled tap units of one (tile, slab) pair, expanded inside conv_halo_kernel with NKS = 2 or 1 (k-steps
-// per unit). A unit is 2 * NKS PHASES, each closed by an s_barrier:
-//   R(k): fetch the 4 pixel + NF weight fragments of k-step k (ds_read_b128), wait for the
-//         fragments (lgkmcnt(0): also closes the write-after-read window of the ring stage / patch buffer that the next
-//         DMA overwrites) and, in the unit's last R phase, s_waitcnt vmcnt(N), N = the DMA operations this wave has issued
-//         in this unit so far: everything issued in earlier units has landed, the unit's own prefetches stay in flight
-//         (vmcnt retires loads in order; the epilogue's own loads / stores, issued after them, only make the wait stricter);
-//         the unit's last R phase also computes the NEXT unit's fragment addresses while its reads are in flight;
-//   M(k): the NF * 4 MFMAs of k-step k, back to back, with two LDS-DMA pieces issued between its halves and NOTHING else:
-//         20 address VALU instructions interleaved with the 24 MFMAs made the phase 690 instead of 380 cycles (s_memtime).
-// DMA pieces of a unit, in issue order: the patch piece of the NEXT pair and weight piece 0 of unit g+2 (M0), weight pieces
-// 1, 2 (M1): an LDS-DMA issue costs the wave ~100-180 cycles next to ds_reads in flight, but next to nothing between MFMAs. A piece that does not exist goes, all lanes out of range, to the dummy region, so every wave issues the same
-// number of operations per unit.
+//     tap costs 4 VALU for the base address + 3 per fragment (offset, v_bfe_i32 of the tap-valid bit, v_bfi_b32 select
+//     of the zero row) + 1 per fragment for the second k-step (address ^ 64);
+//   * a patch piece's source offset is one v_add of a lane constant and a per-unit scalar (rows outside the tensor wrap
+//     to / land behind num_records and come back as zeros).
+// The 9 tap units of one (tile, slab) pair are expanded inside conv_halo_kernel with NKS = 2 or 1 (k-steps per unit: 1
+// for a 32-channel last slab). A unit is TWO PHASES, each closed by an s_barrier:
+//   R: (first unit of a tile: epilogue of the previous tile, zero the accumulators;) fetch the 4 pixel + NF weight
+//      fragments of every k-step (ds_read_b128); store the operands the PREVIOUS unit loaded (ds_write_b128: one patch piece
+//      of the next pair, NWP weight pieces of unit g+1 -- pieces that do not exist go to a 1 KiB dummy region so that the
+//      instruction stream has no branch); compute the NEXT unit's fragment addresses; s_waitcnt lgkmcnt(0): the fragments
+//      are there, and this wave's reads / writes of the ring stage and patch buffer are complete before anyone passes the
+//      barrier (the next writer of a stage is two phases away);
+//   M: the NKS * NF * 4 MFMAs, back to back, with this unit's buffer loads (patch piece of the next pair, weights of unit
+//      g+2) between their quarters and NOTHING else: 20 address VALU instructions interleaved with 24 MFMAs made a phase
+//      690 instead of 380 cycles (s_memtime).
 // Waves 4-7 run ONE PHASE BEHIND waves 0-3 (an extra barrier before the loop, see the kernel): wave w and w + 4 share a
-// SIMD, so one of them is always in an M phase while the other is in an R phase -- the matrix pipe sees back-to-back
-// MFMAs and the LDS sees the reads of four waves at a time. The first R phase of a tile runs the previous tile's epilogue.
+// SIMD, so one of them is in its M phase while the other is in its R phase.
 #ifdef HL_TIMING
 __device__ __forceinline__ unsigned long long hl_clock() {
     unsigned long long t;
@@ -111,9 +110,9 @@ __device__ __forceinline__ unsigned long long hl_clock() {
 }
 #define HL_PHASE_END() \
                 __builtin_amdgcn_sched_barrier(0); \
-                { const unsigned long long n_ = hl_clock(); tacc[2 * (tph & 3)] += n_ - tlast; tlast = n_; } \
+                { const unsigned long long n_ = hl_clock(); tacc[2 * (tph & 1)] += n_ - tlast; tlast = n_; } \
                 __builtin_amdgcn_s_barrier(); \
-                { const unsigned long long n_ = hl_clock(); tacc[2 * (tph & 3) + 1] += n_ - tlast; tlast = n_; ++tph; } \
+                { const unsigned long long n_ = hl_clock(); tacc[2 * (tph & 1) + 1] += n_ - tlast; tlast = n_; ++tph; } \
                 __builtin_amdgcn_sched_barrier(0);
 #else
 #define HL_PHASE_END() \
@@ -121,18 +120,6 @@ __device__ __forceinline__ unsigned long long hl_clock() {
                 __builtin_amdgcn_s_barrier(); \
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-#define HL_MFMAS(A0, A1) \
-_Pragma("unroll") \
-                for (int a = A0; a < A1; ++a) \
-_Pragma("unroll") \
-                    for (int b = 0; b < 4; ++b) \
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
-                            __builtin_bit_cast(bf16x8_t, wb[a]), __builtin_bit_cast(bf16x8_t, xa[b]), acc[a][b], 0, 0, 0);
-#ifdef HL_X_EMPTYR
-#define HL_NEXT_ADDR()
-#define HL_PVOFF(a, b, c, d) OOB
-#else
-#define HL_PVOFF(a, b, c, d) patch_piece_voff(a, b, c, d)
 #define HL_NEXT_ADDR() \
                 if (t < 8) { \
                     tap_addr(pbo, t + 1); \
@@ -140,22 +127,15 @@ _Pragma("unroll") \
                     if (ns == 0 && nvalid) setup_masks(nm0); \
                     tap_addr(npbo, 0); \
                 }
-#endif
-#ifdef HL_X_NOVM
-#define HL_WAIT_R1() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-#define HL_WAIT_R1() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-#endif
-#if defined(HL_X_NOREAD) || defined(HL_X_EMPTYR)
-#define HL_LD(dst, adr) asm volatile("" : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w) : "v"(adr));
-#else
 #define HL_LD(dst, adr) dst = *reinterpret_cast<const uint4*>(smem + (adr));
-#endif
-#ifdef HL_X_NOPRIO
-#define HL_PRIO(x)
-#else
 #define HL_PRIO(x) __builtin_amdgcn_s_setprio(x);
-#endif
+#define HL_MFMAS2(WB_, XA_, A0, A1) \
+_Pragma("unroll") \
+                for (int a = A0; a < A1; ++a) \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; ++b) \
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
+                            __builtin_bit_cast(bf16x8_t, WB_[a]), __builtin_bit_cast(bf16x8_t, XA_[b]), acc[a][b], 0, 0, 0);
 #define HL_UNITS(NKS) \
 _Pragma("unroll") \
             for (int t = 0; t < 9; ++t) { \
@@ -174,39 +154,35 @@ _Pragma("unroll") \
                 const unsigned wbase = wl + (unsigned)((t % 3) * WB); \
                 const unsigned wsrc = t + 2 < 9 ? wso : nwso; \
                 const int wtap = t + 2 < 9 ? t + 2 : t + 2 - 9; \
+                const int tp = (t + 8) % 9;                       /* the unit whose loads are stored now */ \
 _Pragma("unroll") \
                 for (int b = 0; b < 4; ++b) { HL_LD(xa[b], a0[b]) } \
 _Pragma("unroll") \
                 for (int a = 0; a < NF; ++a) { HL_LD(wb[a], wbase + (unsigned)(a * 2048)) } \
-                const unsigned pvoff = HL_PVOFF(npix0, ncbo, nchan_ok, t * 8 + wid); \
-                if (NKS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-                else { \
-                    HL_NEXT_ADDR() \
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                if (NKS == 2) { \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; ++b) { HL_LD(xa1[b], a0[b] ^ 64u) } \
+_Pragma("unroll") \
+                    for (int a = 0; a < NF; ++a) { HL_LD(wb1[a], (wbase ^ 64u) + (unsigned)(a * 2048)) } \
                 } \
+                store_patch_piece(preg, tp, tp == 8 ? cpst_v : npst_v); \
+                store_weights(wreg, (tp + 2) % 9, 0, NWP); \
+                HL_NEXT_ADDR() \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                 HL_PRIO(0) \
                 HL_PHASE_END() \
-                HL_MFMAS(0, NF / 2) \
-                issue_patch_piece(pvoff, t * 8 + wid, npbo); \
-                if (NKS == 2) issue_weights(wsrc, wtap, 0, 1); \
-                else issue_weights(wsrc, wtap, 0, NWP); \
-                HL_MFMAS(NF / 2, NF) \
-                HL_PHASE_END() \
+                HL_MFMAS2(wb, xa, 0, NF / 2) \
+                preg = load_patch_piece(npl_v, nsp, t); \
+                load_weights(wreg, wsrc, wtap, 0, 1); \
+                HL_MFMAS2(wb, xa, NF / 2, NF) \
                 if (NKS == 2) { \
-                    HL_PRIO(2) \
-_Pragma("unroll") \
-                    for (int b = 0; b < 4; ++b) { HL_LD(xa[b], a0[b] ^ 64u) } \
-_Pragma("unroll") \
-                    for (int a = 0; a < NF; ++a) { HL_LD(wb[a], (wbase ^ 64u) + (unsigned)(a * 2048)) } \
-                    HL_NEXT_ADDR() \
-                    HL_WAIT_R1() \
-                    HL_PRIO(0) \
-                    HL_PHASE_END() \
-                    HL_MFMAS(0, NF / 2) \
-                    issue_weights(wsrc, wtap, 1, NWP); \
-                    HL_MFMAS(NF / 2, NF) \
-                    HL_PHASE_END() \
+                    HL_MFMAS2(wb1, xa1, 0, NF / 2) \
+                    load_weights(wreg, wsrc, wtap, 1, NWP); \
+                    HL_MFMAS2(wb1, xa1, NF / 2, NF) \
+                } else { \
+                    load_weights(wreg, wsrc, wtap, 1, NWP); \
                 } \
+                HL_PHASE_END() \
             }
 
 template <int NF, int EPI>
@@ -249,6 +225,13 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
     const int pch = dq ^ (dr & 6);                         // logical chunk this lane fetches of a patch row (piece rows start at a multiple of 8)
     const unsigned pl_off = (unsigned)(pch << 4);
     const bool pl_last_ok = (G.S - 1) * 64 + pch * 8 < P.Cin;      // upper half of a 32-channel last slab reads as zeros
+    // patch piece t*8 + wid of a pair, row (t*64 + wid*8 + dr): byte offset = lane part + a per-unit SCALAR part
+    // ((first pixel + t*64) * ldb + slab*128, negative before the tensor). One v_add per piece; rows outside the tensor
+    // wrap to / land at >= num_records and read as zeros (halo_geom: tensor < 1 GiB, (W + 2) * ldb < 1 MiB), and so does
+    // the lane part HL_VOOB of the lanes whose channels lie behind Cin in a 32-channel last slab.
+    constexpr unsigned HL_VOOB = 0x80100000u;
+    const unsigned pl_v = (unsigned)((wid * 8 + dr) * (int)ldb) + pl_off;
+    const unsigned pl_v_last = pl_last_ok ? pl_v : HL_VOOB;
     const unsigned wdst = lds0 + (unsigned)(wid * 1024);   // + stage + j*8192: this wave's weight pieces
 
     // ---- fragment read addresses -----------------------------------------------------------------------------
@@ -379,29 +362,56 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
             a0[b] = hl_bfi(ok, adr + (unsigned)(b * 2048), zadr);
         }
     };
-    // weights of (channel-tile offset wso = (n0*Kp + slab*64)*2, tap k) into ring stage k % 3
-    auto issue_weights = [&](unsigned wso, int k, int j0, int j1) __attribute__((always_inline)) {
-#ifdef HL_X_NOWDMA
-        return;
-#endif
+    // ---- operand transport: global -> VGPR (buffer loads, issued between the MFMAs of an M phase) -> LDS (ds_write_b128 in
+    // the R phases of the NEXT unit). The LDS image is the lane-linear one an LDS-DMA would produce (piece base + lane*16,
+    // swizzle on the source address). Why not LDS-DMA, which this kernel used first: every buffer_load ... lds stalled its
+    // wave for 100-300 cycles inside the MFMA stream (ablation at B=80, 192 channels: 81 us with DMA, 62 us without any
+    // transport, reads + address arithmetic included); a plain buffer load costs a few issue slots and the compiler counts
+    // the waits (vmcnt(2) at every store: two phases of latency tolerance).
+    const unsigned lane16 = (unsigned)lane << 4;
+    const unsigned wst_v = W_OFF + (unsigned)(wid * 1024) + lane16;        // + stage*WB + j*8192
+    const unsigned pst_v = P_OFF + (unsigned)(wid * 1024) + lane16;        // + buffer + t*8192
+    // weights of (channel-tile offset wso = (n0*Kp + slab*64)*2, tap k): pieces j0 <= j < j1 of this wave
+    auto load_weights = [&](u32x4 (&wr)[NWP], unsigned wso, int k, int j0, int j1) __attribute__((always_inline)) {
         const unsigned soff = wso + (unsigned)k * C2;
-        const unsigned dst = wdst + W_OFF + (unsigned)((k % 3) * WB);
 #pragma unroll
         for (int j = 0; j < NWP; ++j)
-            if (j >= j0 && j < j1)
-                hl_dma16(rs_w, wvoff[j], soff, wid + 8 * j < BN / 8 ? dst + (unsigned)(j * 8192) : lds0 + D_OFF);
+            if (j >= j0 && j < j1) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[j], soff, 0);
     };
-    // piece pc of the patch whose first row is pixel pix0 (may be negative), channel byte offset cbo, into buffer pbo
+    // ... into ring stage k % 3 (a piece behind the tile's BN rows -- BN = 96, waves 4-7, j = 1 -- goes to the dummy region)
+    auto store_weights = [&](const u32x4 (&wr)[NWP], int k, int j0, int j1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+            if (j >= j0 && j < j1) {
+                const unsigned dst = wid + 8 * j < BN / 8 ? wst_v + (unsigned)((k % 3) * WB + j * 8192) : D_OFF + lane16;
+                *reinterpret_cast<u32x4*>(smem + dst) = wr[j];
+            }
+    };
+    // piece pc of the patch whose first row is pixel pix0 (may be negative), channel byte offset cbo
     auto patch_piece_voff = [&](int pix0, unsigned cbo, bool chan_ok, int pc) __attribute__((always_inline)) {
         const int pix = pix0 + pc * 8 + dr;
         const unsigned off = __umul24((unsigned)pix, ldb) + (cbo + pl_off);
         const bool ok = (unsigned)pix < (unsigned)G.Mtot && chan_ok && pc < G.npieces;
         return ok ? off : OOB;
     };
+    // (unit loop) piece t*8 + wid: lane part lv (pl_v or pl_v_last) + scalar part sp of the next pair + t*64 rows
+    auto load_patch_piece = [&](unsigned lv, unsigned sp, int t) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_x, lv + (sp + (unsigned)(t * 64) * ldb), 0, 0);
+    };
+    // ... loaded in unit tu, into the patch buffer at byte offset pbo (pieces behind the patch: dummy region)
+    auto store_patch_piece = [&](const u32x4& pr, int tu, unsigned pv) __attribute__((always_inline)) {
+        const int pc = tu * 8 + wid;
+        const unsigned dst = pc < G.npieces ? pv + (unsigned)(tu * 8192) : D_OFF + lane16;
+        *reinterpret_cast<u32x4*>(smem + dst) = pr;
+    };
+    // (prologue only) LDS-DMA versions
+    auto issue_weights = [&](unsigned wso, int k) __attribute__((always_inline)) {
+        const unsigned soff = wso + (unsigned)k * C2;
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+            hl_dma16(rs_w, wvoff[j], soff, wid + 8 * j < BN / 8 ? wdst + W_OFF + (unsigned)((k % 3) * WB + j * 8192) : lds0 + D_OFF);
+    };
     auto issue_patch_piece = [&](unsigned voff, int pc, unsigned pbo) __attribute__((always_inline)) {
-#ifdef HL_X_NOPDMA
-        return;
-#endif
         hl_dma16(rs_x, voff, 0u, pc < G.npieces ? lds0 + P_OFF + pbo + (unsigned)(pc * 1024) : lds0 + D_OFF);
     };
 
@@ -411,14 +421,19 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
         const unsigned wso = (unsigned)(((it % G.tiles_n) * BN * P.Kp) * 2);
         for (int i = 0; i < G.NPU; ++i)
             issue_patch_piece(patch_piece_voff(m0 - (W + 1), 0u, G.S > 1 || pl_last_ok, i * 8 + wid), i * 8 + wid, 0u);
-        issue_weights(wso, 0, 0, NWP);
-        issue_weights(wso, 1, 0, NWP);
+        issue_weights(wso, 0);
         setup_masks(m0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    uint4 xa[4], wb[NF];
+    uint4 xa[4], wb[NF], xa1[4], wb1[NF];
+    u32x4 wreg[NWP], preg;                                 // operands in flight: loaded in unit g, stored in unit g+1
+    {
+        const unsigned wso0 = (unsigned)(((it % G.tiles_n) * BN * P.Kp) * 2);
+        load_weights(wreg, wso0, 1, 0, NWP);               // what "unit -1" would have loaded: weights of unit 1, no patch piece
+        preg = load_patch_piece(pl_v, 0x80000000u, 0);     // (all lanes out of range)
+    }
 #ifdef HL_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = hl_clock();
     int tph = 0;
@@ -442,10 +457,11 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
         const int ntile_m = nit / G.tiles_n;
         const int nm0 = ntile_m * HL_TP, nn0 = (nit - ntile_m * G.tiles_n) * BN;
         const unsigned nwso = nvalid ? (unsigned)((nn0 * P.Kp + ns * 64) * 2) : wso;       // (no next pair: any valid address)
-        const int npix0 = nvalid ? nm0 - (W + 1) : (1 << 30);                              // (no next pair: every lane out of range)
-        const unsigned ncbo = (unsigned)(ns * 128);
-        const bool nchan_ok = ns < G.S - 1 || pl_last_ok;
+        // (no next pair: every lane out of range)
+        const unsigned nsp = nvalid ? (unsigned)((nm0 - (W + 1)) * (int)ldb + ns * 128) : 0x80000000u;
+        const unsigned npl_v = ns < G.S - 1 ? pl_v : pl_v_last;
         const unsigned npbo = pbo ^ (unsigned)PB;          // patch buffers at 0 and PB
+        const unsigned npst_v = pst_v + npbo, cpst_v = pst_v + pbo;
         // the 9 tap units of this pair; NKS (k-steps per unit: 2, or 1 for a 32-channel last slab) is a compile-time
         // constant of the unrolled sequence, so that no fragment read sits in a conditional block (the compiler's
         // counted lgkmcnt before the first MFMA otherwise has to assume the shorter path and waits for the k-step-1 reads)
@@ -469,11 +485,13 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-static int g_halo = -1;            // Y5M_CONV_HALO=0: keep the 3x3 stride-1 layers on the tiled kernel (A/B runs)
+static int g_halo = -1;            // Y5M_CONV_HALO: 0 = tiled kernel everywhere (A/B runs), 1 (default) = 192-channel tiles only, 2 = also the
+                                   // 96-channel tile (N = 96: 24 MFMAs per wave and phase do not cover the other group's R
+                                   // phase -- 490-580 TFLOP/s against 520-670 for the tiled kernel on 96 -> 96 @ 80x80)
 static int g_halo_cus = 0;
 
 static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
-    if (g_halo < 0) { const char* e = getenv("Y5M_CONV_HALO"); g_halo = (e && e[0] == '0') ? 0 : 1; }
+    if (g_halo < 0) { const char* e = getenv("Y5M_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
     if (!g_halo || dtype != Y5M_BF16) return false;
     if (P.th != 3 || P.tw != 3 || P.sy != 1 || P.sx != 1) return false;
     if (!((P.dh0 == -1 && P.dhs == 1) || (P.dh0 == 1 && P.dhs == -1))) return false;
@@ -485,6 +503,7 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     if (P.Cin < 64 || P.Cin % 32 != 0 || P.ldin % 8 != 0) return false;
     if (P.N % 96 != 0) return false;
     BN = (P.N % 192 == 0 && P.Cin % 64 == 0) ? 192 : 96;
+    if (BN == 96 && g_halo < 2) return false;
     if (P.Np < (P.N + BN - 1) / BN * BN) return false;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return false;      // 16-byte output pieces
     if (P.res && P.ldres % 4 != 0) return false;
@@ -492,7 +511,7 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     if (P.Kp < 8 * P.Cin + S * 64) return false;            // the last unit's 128-byte weight rows stay inside the packed rows
     const long long Mtot = (long long)P.B * P.Hin * P.Win;
     if (Mtot >= (1ll << 24) || (long long)P.ldin * 2 >= (1ll << 24)) return false;           // 24-bit multiply in the patch address
-    if (Mtot * P.ldin * 2 >= (1ll << 31)) return false;
+    if (Mtot * P.ldin * 2 >= (1ll << 30) || (long long)(P.Win + 2) * P.ldin * 2 >= (1ll << 20)) return false;   // see pl_v in the kernel
     const int PR = HL_TP + 2 * P.Win + 2;
     G.PR8 = (PR + 7) / 8 * 8;
     G.npieces = G.PR8 / 8;
