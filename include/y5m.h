@@ -136,6 +136,17 @@ int y5m_compute_loss(const float* const p[3], float* const grad[3], int B, int n
  * YOLO_LOSS.build_targets (loss.py:101-192): obj==1 positives, obj==-1 "ignore" cells whose BCE target
  * stays -1 (reference behaviour, loss.py:220). rows_max >= number of positives per scale.
  * loss_out[4] as y5m_compute_loss; NaN when a scale has no positives (loss.py:212). */
+/* Replaces YOLO_LOSS.build_targets (loss.py:101-192, the per-image Python loop over boxes x 9 anchors the reference
+ * runs on the host every step) together with iou_width_height (utils/bboxes_utils.py:6-29) for a whole batch:
+ * boxes (nt,5) float64 rows [cls, x, y, w, h] of all images back to back (the reference's collate_fn arrays),
+ * img_off (B+1) int32 row ranges per image; ny/nx/stride host arrays of the 3 scales; dense[i] (B,3,ny_i,nx_i,6) f32,
+ * fully overwritten: [x_cell, y_cell, w_cell, h_cell, obj (1 | -1 ignore | 0), class]. anchors_in (3,3,2) f32 is the
+ * loss object's anchor state BEFORE this call, anchors_out (a different buffer) receives the state after it: the
+ * reference divides its anchors by 640 in place once per box (bboxes_utils.py:18) and parity is defined on that
+ * behaviour, bit for bit (first-come slot claims, stable descending anchor order, float64 cell arithmetic). */
+int y5m_yolo_build_targets(const double* boxes, const int32_t* img_off, int B, const int* ny, const int* nx,
+                           const int* stride, const float* anchors_in, float* anchors_out, float ignore_iou_thresh,
+                           float* const dense[3], void* stream);
 size_t y5m_compute_loss_dense_workspace_bytes(int B, int naxs, const int* ny, const int* nx, int rows_max);
 int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
                            int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,

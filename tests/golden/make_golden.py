@@ -475,8 +475,45 @@ def g8_input_stage():
     save("g8_input_stage", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+def g12_yolo_build_targets(model):
+    """YOLO_LOSS.build_targets of the REAL reference at batch scale: a fresh loss object, two calls of 16 images x 8
+    boxes at 320x320 (cell grids 40 / 20 / 10). 256 boxes in a row walk the loss object's anchors through the whole
+    in-place decay: real anchors, shrinking anchors, fp32 denormals, exact zeros -- i.e. distinct IoUs, then
+    nine-way ties in the anchor ranking. Includes boxes that share a cell (slot already taken) and a pair of wide boxes
+    per image (ignore cells). Stored sparsely: the non-zero cells of every scale and the anchor state after each call."""
+    lf = R.YOLO_LOSS(model, rect_training=False)
+    shapes = [(40, 40), (20, 20), (10, 10)]
+    B, nb = 16, 8
+    rng = np.random.default_rng(12)
+    out = {"shapes": np.array(shapes, np.int64), "B": np.array(B), "anchors0": lf.anchors.clone().numpy()}
+    p = [torch.zeros(1, 3, ny, nx, 85) for (ny, nx) in shapes]
+    for call in range(2):
+        dense = [[] for _ in range(3)]
+        for b in range(B):
+            arr = np.zeros((nb, 5), np.float64)
+            arr[:, 0] = rng.integers(0, 80, nb)
+            arr[:, 1:3] = rng.uniform(0.02, 0.98, (nb, 2))
+            arr[:, 3:5] = rng.uniform(0.02, 0.7, (nb, 2))
+            arr[1, 1:3] = arr[0, 1:3]                        # same cell as box 0 on every scale
+            arr[2, 3:5] = rng.uniform(0.5, 0.95, 2)          # wide boxes: several anchors above the ignore threshold
+            arr[3, 3:5] = arr[2, 3:5] * rng.uniform(0.9, 1.1, 2)
+            arr[3, 1:3] = np.clip(arr[2, 1:3] + rng.uniform(-0.01, 0.01, 2), 0.02, 0.98)
+            out[f"{call}/boxes{b}"] = arr
+            tg = lf.build_targets(p, arr, (320, 320))
+            for i in range(3):
+                dense[i].append(tg[i].numpy())
+        out[f"{call}/anchors_after"] = lf.anchors.clone().numpy()
+        for i in range(3):
+            d = np.stack(dense[i], 0)                        # (B,3,ny,nx,6)
+            nz = np.argwhere(np.any(d != 0, axis=-1)).astype(np.int32)
+            out[f"{call}/nz{i}"] = nz
+            out[f"{call}/val{i}"] = d[tuple(nz.T)].astype(np.float32)
+    save("g12_yolo_build_targets", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -490,3 +527,4 @@ if __name__ == "__main__":
     if "g9" in which: g9_nms_aladdin()
     if "g10" in which: g10_config0(model)
     if "g11" in which: g11_eval_path(model)
+    if "g12" in which: g12_yolo_build_targets(model)

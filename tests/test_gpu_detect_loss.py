@@ -309,6 +309,41 @@ def test_yolo_loss_golden_pinned_sequence(golden, anchors):
             assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, (call, i)
 
 
+def test_yolo_build_targets_native_batch_golden(golden):
+    """y5m_yolo_build_targets (one launch per batch) against the REAL reference's per-image Python loop: two calls of 16
+    images x 8 boxes on one loss object -- 256 boxes walk the in-place anchor decay through real anchors, denormals and
+    exact zeros (nine-way ties in the anchor ranking), boxes sharing a cell, ignore cells. Dense targets (all three
+    scales, every float) and the anchor state after each call: bit-exact. Also the empty image and the all-empty batch."""
+    from yolov5m_amd.loss import YOLO_LOSS
+    g = golden("g12_yolo_build_targets")
+    B = int(g["B"])
+    shapes = [tuple(int(v) for v in s) for s in g["shapes"]]
+    lf = YOLO_LOSS(_StubModel(torch.from_numpy(g["anchors0"])), rect_training=False)
+    for call in range(2):
+        boxes = [g[f"{call}/boxes{b}"] for b in range(B)]
+        dense = lf._build_targets_native(shapes, boxes)
+        for i in range(3):
+            ref = np.zeros(tuple(dense[i].shape), np.float32)
+            ref[tuple(g[f"{call}/nz{i}"].T)] = g[f"{call}/val{i}"]
+            got = dense[i].cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (call, i, int((got != ref).sum()))
+        assert np.array_equal(lf.anchors.numpy().view(np.uint32), g[f"{call}/anchors_after"].view(np.uint32))
+    # images without boxes leave zeros and do not advance the anchor state
+    before = lf.anchors.numpy().copy()
+    dense = lf._build_targets_native(shapes, [np.zeros((0, 5)), g["0/boxes0"][:0]])
+    assert all(float(d.abs().sum()) == 0.0 for d in dense)
+    assert np.array_equal(lf.anchors.numpy(), before)
+    # a fresh object, mixed empty / non-empty images == the oracle, image by image
+    lf2 = YOLO_LOSS(_StubModel(torch.from_numpy(g["anchors0"])), rect_training=False)
+    ref2 = loss_ref.YoloLossRef(g["anchors0"])
+    boxes = [g["0/boxes0"], np.zeros((0, 5)), g["0/boxes1"][:3], np.zeros((0, 5)), g["0/boxes2"]]
+    dense = lf2._build_targets_native(shapes, boxes)
+    tg = [ref2.build_targets(shapes, b) for b in boxes]
+    for i in range(3):
+        assert np.array_equal(dense[i].cpu().numpy(), torch.stack([t[i] for t in tg], 0).numpy())
+    assert np.array_equal(lf2.anchors.numpy(), ref2.anchors.numpy())
+
+
 def test_yolo_loss_single_scale_and_nan(anchors):
     from yolov5m_amd.loss import YOLO_LOSS
     from oracle.loss_ref import YoloLossRef

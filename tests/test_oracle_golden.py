@@ -75,6 +75,30 @@ def test_g4_yolo_loss_pinned_sequence(golden):
             np.testing.assert_allclose(p[i].grad.numpy(), g[f"{call}/g{i}"], rtol=1e-5, atol=1e-9)
 
 
+def _g12_dense(g, call, i):
+    B = int(g["B"])
+    ny, nx = [tuple(s) for s in g["shapes"]][i]
+    d = np.zeros((B, 3, ny, nx, 6), np.float32)
+    nz = g[f"{call}/nz{i}"]
+    d[tuple(nz.T)] = g[f"{call}/val{i}"]
+    return d
+
+
+def test_g12_yolo_build_targets_batch_sequence(golden):
+    """the oracle's YOLO_LOSS.build_targets against the real reference over 256 boxes in a row (the whole anchor decay:
+    distinct IoUs, denormals, nine-way ties): dense targets and the anchor state, bit for bit"""
+    g = golden("g12_yolo_build_targets")
+    lf = loss_ref.YoloLossRef(g["anchors0"])
+    shapes = [tuple(s) for s in g["shapes"]]
+    B = int(g["B"])
+    for call in range(2):
+        tg = [lf.build_targets(shapes, g[f"{call}/boxes{b}"]) for b in range(B)]
+        for i in range(3):
+            got = torch.stack([t[i] for t in tg], 0).numpy()
+            assert np.array_equal(got, _g12_dense(g, call, i)), (call, i)
+        assert np.array_equal(lf.anchors.numpy(), g[f"{call}/anchors_after"])
+
+
 @pytest.mark.parametrize("tag,shape", [("s64", (1, 64, 64)), ("s96x128", (2, 96, 128))])
 def test_g5_model_forward(golden, tag, shape):
     g = golden("g5_model")

@@ -103,6 +103,8 @@ _SIGS = {
     "y5m_compute_loss_sparse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                  c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
+    "y5m_yolo_build_targets": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                       c_void_p, c_void_p]),
     "y5m_compute_loss_dense_workspace_bytes": (c_size_t, [c_int, c_int, c_void_p, c_void_p, c_int]),
     "y5m_compute_loss_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
                                        c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,

@@ -534,3 +534,102 @@ extern "C" int y5m_compute_loss_dense(const float* const p[3], float* const grad
     return run_loss(p, grad, dense, B, naxs, ny, nx, nc, tg, nt, balance, lambda_box, lambda_obj, lambda_cls, loss_out, w,
                     ws_bytes - used, st);
 }
+
+// =================================================================================================
+// YOLO_LOSS.build_targets (reference loss.py:101-192) + iou_width_height (utils/bboxes_utils.py:6-29)
+// =================================================================================================
+// One workgroup per image. The assignment is sequential by construction in the reference -- boxes claim
+// (scale, anchor, cell) slots first come first served, and EVERY box divides the loss object's anchors by 640 in
+// place before it is matched (bboxes_utils.py:18) -- so lane 0 walks the image's boxes in order; the
+// other lanes only clear the image's slices of the dense targets. Image b starts from the anchor state after
+// off[b] boxes: the decay is replayed (at most ~17 divisions until fp32 reaches exact zeros, where it stops).
+// Arithmetic as torch evaluates the reference's expressions: anchors fp32, true division by 640; the box's w, h enter
+// the min() as fp32 (a 0-dim float64 tensor does not promote a dimensioned float32 one), w*h is a float64 product
+// rounded to fp32 when added; cell indices and offsets are float64 (numpy scalars) and rounded once on the store;
+// argsort(descending) of 9 values = libstdc++ insertion sort = stable, NaN first. Compiled with -ffp-contract=off.
+struct YbtArgs {
+    float* dense[3];
+    int ny[3], nx[3], stride[3];
+};
+
+__device__ __forceinline__ bool ybt_before(float x, float y) {      // ATen KeyValueCompDesc
+    return (isnan(x) && !isnan(y)) || x > y;
+}
+
+__global__ __launch_bounds__(256) void yolo_build_targets_kernel(const double* __restrict__ boxes, const int* __restrict__ off,
+                                                                 int B, YbtArgs A, const float* __restrict__ anc_in,
+                                                                 float* __restrict__ anc_out, float ignore_thr) {
+    const int b = blockIdx.x;
+    for (int s = 0; s < 3; ++s) {
+        const int64_t n = (int64_t)3 * A.ny[s] * A.nx[s] * 6;
+        float* d = A.dense[s] + (int64_t)b * n;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float a[18];
+    for (int i = 0; i < 18; ++i) a[i] = anc_in[i];
+    const int k0 = off[b], k1 = off[b + 1];
+    for (int k = 0; k < k0; ++k) {
+        bool any = false;
+        for (int i = 0; i < 18; ++i) { a[i] = __fdiv_rn(a[i], 640.0f); any |= a[i] != 0.f; }
+        if (!any) break;                                    // exact zeros (or NaN-free fixed point): further steps change nothing
+    }
+    for (int k = k0; k < k1; ++k) {
+        for (int i = 0; i < 18; ++i) a[i] = __fdiv_rn(a[i], 640.0f);               // bboxes_utils.py:18
+        const double cls = boxes[k * 5 + 0], x = boxes[k * 5 + 1], y = boxes[k * 5 + 2], w = boxes[k * 5 + 3], h = boxes[k * 5 + 4];
+        const float w32 = (float)w, h32 = (float)h, wh32 = (float)(w * h);
+        float iou[9];
+        int order[9];
+        for (int j = 0; j < 9; ++j) {
+            const float st = (float)A.stride[j / 3];
+            const float aw = a[2 * j] * st, ah = a[2 * j + 1] * st;                // :20-23
+            const float mw = (w32 != w32 || aw != aw) ? NAN : (w32 < aw ? w32 : aw);
+            const float mh = (h32 != h32 || ah != ah) ? NAN : (h32 < ah ? h32 : ah);
+            const float inter = mw * mh;                                           // :25-27
+            const float uni = (wh32 + aw * ah) - inter;                            // :28-30
+            iou[j] = __fdiv_rn(inter, uni);
+            // insertion into the sorted prefix (stable: an equal key never moves in front of an earlier one)
+            int pos = j;
+            while (pos > 0 && ybt_before(iou[j], iou[order[pos - 1]])) { order[pos] = order[pos - 1]; --pos; }
+            order[pos] = j;
+        }
+        bool has[3] = {false, false, false};
+        for (int q = 0; q < 9; ++q) {
+            const int idx = order[q], s = idx / 3, an = idx - s * 3;
+            const int ny = A.ny[s], nx = A.nx[s];
+            const int i = (int)((double)ny * y), j = (int)((double)nx * x);        // :152
+            if (i < 0 || i >= ny || j < 0 || j >= nx) continue;                    // (the reference raises IndexError here)
+            float* cell = A.dense[s] + ((((int64_t)b * 3 + an) * ny + i) * nx + j) * 6;
+            const bool taken = cell[4] != 0.f;
+            if (!taken && !has[s]) {
+                cell[4] = 1.f;
+                cell[0] = (float)((double)nx * x - (double)j);
+                cell[1] = (float)((double)ny * y - (double)i);
+                cell[2] = (float)(w * (double)nx);
+                cell[3] = (float)(h * (double)ny);
+                cell[5] = (float)(int)cls;
+                has[s] = true;
+            } else if (!taken && iou[idx] > ignore_thr) {
+                cell[4] = -1.f;                                                    // :190
+            }
+        }
+    }
+    if (b == B - 1)
+        for (int i = 0; i < 18; ++i) anc_out[i] = a[i];
+}
+
+extern "C" int y5m_yolo_build_targets(const double* boxes, const int32_t* img_off, int B, const int* ny, const int* nx,
+                                      const int* stride, const float* anchors_in, float* anchors_out, float ignore_iou_thresh,
+                                      float* const dense[3], void* stream) {
+    Y5M_REQUIRE(B > 0 && img_off && anchors_in && anchors_out && anchors_in != anchors_out, "arguments");
+    YbtArgs A;
+    for (int s = 0; s < 3; ++s) {
+        Y5M_REQUIRE(dense[s] && ny[s] > 0 && nx[s] > 0, "dense targets");
+        A.dense[s] = dense[s]; A.ny[s] = ny[s]; A.nx[s] = nx[s]; A.stride[s] = stride[s];
+    }
+    hipLaunchKernelGGL(yolo_build_targets_kernel, dim3((unsigned)B), dim3(256), 0, y5m_stream(stream), boxes, img_off, B, A,
+                       anchors_in, anchors_out, ignore_iou_thresh);
+    Y5M_CHECK_LAUNCH("yolo_build_targets_kernel");
+    return Y5M_OK;
+}

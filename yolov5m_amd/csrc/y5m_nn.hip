@@ -327,7 +327,13 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
         __hip_atomic_store(stage + ((size_t)blockIdx.x * 2 + rl) * C + c, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- the block that takes the last ticket of this channel group finalises ---------------------
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // Publish form R1 of the CDNA4 guide (section 6, Guideline 16): write-through (sc1) payload stores -> EVERY storing
+    // wave drains them (explicit s_waitcnt vmcnt(0): inline asm, so the compiler cannot drop it the way it may drop the
+    // wait of a fence it considers redundant) -> workgroup barrier -> ONE lane takes the agent-scope ticket; the last
+    // arriver reads the stage with sc1 loads, which are served from the memory side and cannot hit a stale L1 / foreign-L2
+    // line. No agent-scope fence is needed for data that never sits dirty in an L2 (a fence would write back the whole
+    // per-XCD L2: ~30 us right after a conv).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
         s_last = (__hip_atomic_fetch_add(ctr + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)S - 1) ? 1 : 0;

@@ -86,6 +86,8 @@ class Engine:
     def __init__(self, model, B, H, W, dtype=BF16, training=True, nt_max=0):
         assert H % 32 == 0 and W % 32 == 0, "Width and Height aren't divisible by 32!"   # model.py:211
         self.L = _lib.lib()
+        self.released = False
+        self.key = None                 # the model's plan-cache key (set by YOLOV5m._engine_for)
         self.model = model
         self.B, self.H, self.W = B, H, W
         self.dtype = dtype
@@ -126,6 +128,16 @@ class Engine:
         self._stats_floats = 0
         self._bnws_bytes = 0
         self._build()
+
+    def release(self):
+        """drop every launch closure and tensor of this plan (called by the model's plan cache on eviction). The closures
+        capture `self`, so without this the plan is a reference cycle whose HBM only returns when Python's cyclic GC
+        runs; `released` tells holders of captured graphs (NativeTrainStep) that replaying them would touch freed memory."""
+        self.released = True
+        keep = {"released", "key"}
+        for k in list(self.__dict__):
+            if k not in keep:
+                del self.__dict__[k]
 
     # ------------------------------------------------------------------ allocation helpers
     def _new_act(self, B, H, W, C, need_grad=True):

@@ -1,10 +1,11 @@
 """YOLO_LOSS -- same signature as the reference's loss.py:20-246.
 
-Split exactly as in the reference:
-  * build_targets (loss.py:101-192) is HOST code there (numpy float64 boxes, Python loops, CPU
-    tensors, then `.to(device)` at :70-74) and stays host code here, including the reference's stateful
-    defect: utils/bboxes_utils.py:18 divides `self.anchors` by 640 IN PLACE on every call,
-    so only the first box ever sees the real anchors. Parity is defined on that behaviour.
+  * build_targets (loss.py:101-192: a Python double loop over boxes x 9 anchors per image on the host, the
+    reference's documented hot loop #2) is ONE native launch for the whole batch (y5m_yolo_build_targets: one
+    workgroup per image, float64 box arithmetic, dense targets written on the device), including the
+    reference's stateful defect: utils/bboxes_utils.py:18 divides the loss object's anchors by 640 IN PLACE
+    for every box, so only the first box ever sees the real anchors. Parity is defined on that
+    behaviour, bit for bit; the anchor state lives on the device and `anchors` reads it back.
   * compute_loss (loss.py:195-246) for the 3 scales and its autograd backward run on the MI355X in the
     dense-target variant of the native loss kernels (y5m_compute_loss_dense).
 """
@@ -15,7 +16,6 @@ import numpy as np
 import torch
 
 from . import _lib, config
-from .utils.bboxes_utils import iou_width_height
 
 
 class _DenseLossFn(torch.autograd.Function):
@@ -59,8 +59,9 @@ class YOLO_LOSS:
         self.balance = [4.0, 1.0, 0.4]                                                # :36
         self.nc = model.head.nc
         self.anchors_d = model.head.anchors.clone().detach().contiguous()             # :39
-        self.anchors = model.head.anchors.clone().detach().to("cpu")                  # :40 (decays in place!)
-        self.na = self.anchors.reshape(9, 2).shape[0]
+        # :40 `self.anchors` (decays in place!): device-resident state, two buffers (the kernel reads one, writes the other)
+        self._anc = [self.anchors_d.clone().float().contiguous(), torch.zeros_like(self.anchors_d, dtype=torch.float32)]
+        self.na = self.anchors_d.reshape(9, 2).shape[0]
         self.num_anchors_per_scale = self.na // 3
         self.S = model.head.stride
         self.ignore_iou_thresh = 0.5
@@ -75,13 +76,41 @@ class YOLO_LOSS:
             with open(os.path.join(folder, "loss.csv"), "w") as f:
                 csv.writer(f).writerow(["epoch", "batch_idx", "box_loss", "object_loss", "class_loss"])
 
+    @property
+    def anchors(self):
+        """the reference's CPU `self.anchors` (loss.py:40) after every in-place decay so far"""
+        return self._anc[0].detach().to("cpu")
+
+    def _build_targets_native(self, shapes, boxes_list):
+        """dense targets [(B,3,ny,nx,6)]*3 on the device for a list of per-image (n_i,5) float64 arrays"""
+        L = _lib.lib()
+        dev = self.anchors_d.device
+        B = len(boxes_list)
+        counts = [int(len(b)) for b in boxes_list]
+        off = np.zeros(B + 1, np.int32)
+        off[1:] = np.cumsum(counts)
+        flat = (np.concatenate([np.asarray(b, np.float64).reshape(-1, 5) for b in boxes_list], 0) if off[-1] else
+                np.zeros((1, 5), np.float64))
+        d_boxes = torch.from_numpy(np.ascontiguousarray(flat)).to(dev, non_blocking=True)
+        d_off = torch.from_numpy(off).to(dev, non_blocking=True)
+        dense = [torch.empty((B, self.num_anchors_per_scale, ny, nx, 6), dtype=torch.float32, device=dev) for (ny, nx) in shapes]
+        ny = _lib.int_array([sh[0] for sh in shapes])
+        nx = _lib.int_array([sh[1] for sh in shapes])
+        st = _lib.int_array([int(v) for v in self.S])
+        _lib.check(L.y5m_yolo_build_targets(_lib.ptr(d_boxes), _lib.ptr(d_off), B, ny, nx, st, _lib.ptr(self._anc[0]),
+                                            _lib.ptr(self._anc[1]), float(self.ignore_iou_thresh), _lib.ptr_array(dense),
+                                            _lib.stream_ptr()), "y5m_yolo_build_targets")
+        if off[-1]:
+            self._anc.reverse()                       # the state after this call
+        self._keep = (d_boxes, d_off)                 # until the launch has run
+        return dense
+
     def __call__(self, preds, targets, pred_size, batch_idx=None, epoch=None):
         """reference loss.py:64-99. preds: 3 logits tensors; targets: tuple of per-image ndarrays (n_i,5)
         [cls, x, y, w, h] (reference collate_fn, dataset.py:199-202)."""
         self.batch_idx, self.epoch = batch_idx, epoch
-        tg = [self.build_targets(preds, bboxes, pred_size) for bboxes in targets]                    # :68
-        dev = self.anchors_d.device
-        dense = [torch.stack([t[i] for t in tg], dim=0).to(dev, non_blocking=True).contiguous() for i in range(3)]
+        shapes = [(preds[i].shape[2], preds[i].shape[3]) for i in range(len(self.S))]
+        dense = self._build_targets_native(shapes, list(targets))                                    # :68-74
         rows_max = max(1, sum(len(b) for b in targets))
         p = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous() for t in preds]
         _lib.require_cuda(*p)
@@ -93,32 +122,11 @@ class YOLO_LOSS:
         return loss
 
     def build_targets(self, input_tensor, bboxes, pred_size):
-        """reference loss.py:101-192 for ONE image -> list of 3 CPU tensors (3, ny, nx, 6)."""
+        """reference loss.py:101-192 for ONE image -> list of 3 CPU tensors (3, ny, nx, 6) (the reference's return
+        value; __call__ keeps the batch on the device instead)."""
         shapes = [(input_tensor[i].shape[2], input_tensor[i].shape[3]) for i in range(len(self.S))]
-        targets = [torch.zeros((self.num_anchors_per_scale, ny, nx, 6)) for (ny, nx) in shapes]
-        classes = bboxes[:, 0].tolist() if len(bboxes) else []
-        boxes = bboxes[:, 1:] if len(bboxes) else []
-        for idx, box in enumerate(boxes):
-            iou_anchors = iou_width_height(torch.from_numpy(np.asarray(box[2:4])), self.anchors)     # :120 (in-place decay)
-            anchor_indices = iou_anchors.argsort(descending=True, dim=0)                             # :122
-            x, y, width, height = box
-            has_anchor = [False] * 3
-            for anchor_idx in anchor_indices:
-                scale_idx = int(torch.div(anchor_idx, self.num_anchors_per_scale, rounding_mode="floor"))
-                anchor_on_scale = int(anchor_idx % self.num_anchors_per_scale)
-                scale_y, scale_x = shapes[scale_idx]
-                i, j = int(scale_y * y), int(scale_x * x)                                            # :152
-                anchor_taken = targets[scale_idx][anchor_on_scale, i, j, 4]
-                if not anchor_taken and not has_anchor[scale_idx]:
-                    targets[scale_idx][anchor_on_scale, i, j, 4] = 1
-                    x_cell, y_cell = scale_x * x - j, scale_y * y - i
-                    width_cell, height_cell = width * scale_x, height * scale_y
-                    targets[scale_idx][anchor_on_scale, i, j, 0:4] = torch.tensor([x_cell, y_cell, width_cell, height_cell])
-                    targets[scale_idx][anchor_on_scale, i, j, 5] = int(classes[idx])
-                    has_anchor[scale_idx] = True
-                elif not anchor_taken and iou_anchors[anchor_idx] > self.ignore_iou_thresh:
-                    targets[scale_idx][anchor_on_scale, i, j, 4] = -1                                # :190 ignore
-        return targets
+        dense = self._build_targets_native(shapes, [np.asarray(bboxes, np.float64).reshape(-1, 5)])
+        return [d[0].to("cpu") for d in dense]
 
     def compute_loss(self, preds, targets, anchors, balance):
         """reference loss.py:195-246 for ONE scale -> (loss, logs or None): the same native kernels with

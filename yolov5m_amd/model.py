@@ -7,6 +7,8 @@ re-pointed into ONE flat f32 parameter buffer (and one flat gradient buffer) the
 runs on the GPU, which is what the fused optimizer and the RCCL gradient all-reduce operate on.
 Only YOLOV5m.forward executes: it is a single autograd Function around the native forward/backward.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -223,11 +225,18 @@ class YOLOV5m(nn.Module):
         B, _, H, W = x.shape
         dt = _lib.BF16 if self.compute_dtype == "bf16" else _lib.F32
         key = (B, H, W, dt, self.training)
-        eng = self._engines.get(key)
+        eng = self._engines.pop(key, None)
         if eng is None:
-            if len(self._engines) >= 4:        # bound resident plans (multi-scale training varies H,W)
-                self._engines.pop(next(iter(self._engines)))
-            eng = self._engines[key] = Engine(self, B, H, W, dtype=dt, training=self.training)
+            # bound the resident plans (multi-scale training varies H, W; one training plan at B=64 / 640^2 holds ~40 GB):
+            # least-recently-used eviction with an explicit release, so the evicted plan's HBM is free BEFORE the new
+            # one allocates (a plan is a reference cycle -- its launch closures capture it -- and would otherwise live
+            # until the cyclic GC runs) and a captured graph can never be replayed on freed buffers (Engine.released)
+            cap = max(1, int(os.environ.get("Y5M_ENGINE_CACHE", "4")))
+            while len(self._engines) >= cap:
+                self._engines.pop(next(iter(self._engines))).release()
+            eng = Engine(self, B, H, W, dtype=dt, training=self.training)
+            eng.key = key
+        self._engines[key] = eng               # (re-)insert at the most-recently-used end
         return eng
 
     # ------------------------------------------------------------------ reference API

@@ -123,8 +123,10 @@ class NativeTrainStep:
         self.targets = torch.zeros((nt_max, 6), dtype=torch.float32, device=dev)
         self.d_nt = torch.zeros(1, dtype=torch.int32, device=dev)
         self.loss_out = None
-        self._graph = None
-        self._key = None
+        # captured graphs: one forward+loss+backward graph PER PLAN (keyed by the plan's (B, H, W, dtype, mode) key, held
+        # together with a strong reference to the plan: id(plan) can be reused after a plan is freed), one optimizer graph
+        self._fb_graphs = {}
+        self._opt_graph = None
         self._ws = None
         if self.accumulate > 1:
             self.gacc = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -215,68 +217,73 @@ class NativeTrainStep:
         back to back; grad_hook (the RCCL all-reduce) runs between them on the same stream."""
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
-        key = (id(eng),)
         if self.accumulate > 1:
-            return self._step_accumulate(eng, key)
+            return self._step_accumulate(eng)
         if not self.use_graph:
             self._enqueue_fb(eng)
             if self.grad_hook is not None:
                 self.grad_hook(self.model.flat_grads)
             self._optimizer()
             return self.loss_out
-        if self._graph is None or self._key != key:
+        g1 = self._graph_for(eng)
+        if g1 is None:
             # one eager warm-up step (module loading, kernel attributes), then capture
             self._enqueue_fb(eng)
             if self.grad_hook is not None:
                 self.grad_hook(self.model.flat_grads)
             self._optimizer()
-            torch.cuda.synchronize()
-            try:
-                # thread_local: a RCCL watchdog / other thread touching the HIP runtime must not abort the capture
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                    self._enqueue_fb(eng)
-                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                    self._optimizer()
-                self._graph, self._key = (g1, g2), key
-                return self.loss_out                     # this call WAS the eager step: one call = one step
-            except Exception as e:                       # capture is an optimisation, never a requirement
-                import warnings
-                warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
-                torch.cuda.synchronize()
-                self.use_graph = False
-                eng._pending.clear()
-                return self.loss_out
-        g1, g2 = self._graph
+            self._capture(eng, lambda: self._enqueue_fb(eng))
+            return self.loss_out                         # this call WAS the eager step: one call = one step
         g1.replay()
         if self.grad_hook is not None:
             self.grad_hook(self.model.flat_grads)
-        g2.replay()
+        self._opt_graph.replay()
         return self.loss_out
 
-    def _step_accumulate(self, eng, key):
-        """micro-batch: forward/backward (+ graph replay) then gacc += grads; every `accumulate`-th call the
-        all-reduce hook, clip + Adam on the sum, and gacc = 0"""
-        if self.use_graph and (self._graph is None or self._key != key):
-            self._enqueue_fb(eng)                                  # eager warm-up == this call's micro-batch
-            self.gacc.add_(self.model.flat_grads)
-            torch.cuda.synchronize()
-            try:
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                    self._enqueue_fb(eng)
-                    self.gacc.add_(self.model.flat_grads)
+    def _graph_for(self, eng):
+        """the captured forward+loss+backward graph of this plan, or None. Entries of plans the model has evicted
+        (Engine.released) are dropped here: their buffers are gone."""
+        for k in [k for k, (e, _g) in self._fb_graphs.items() if e.released]:
+            del self._fb_graphs[k]
+        ent = self._fb_graphs.get(eng.key)
+        if ent is not None and ent[0] is eng and self._opt_graph is not None:
+            return ent[1]
+        return None
+
+    def _capture(self, eng, enqueue):
+        torch.cuda.synchronize()
+        try:
+            # thread_local: a RCCL watchdog / other thread touching the HIP runtime must not abort the capture
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                enqueue()
+            if self._opt_graph is None:
+                g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._optimizer()
-                self._graph, self._key = (g1, g2), key
-            except Exception as e:
-                import warnings
-                warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
-                torch.cuda.synchronize()
-                self.use_graph = False
-                eng._pending.clear()
+                self._opt_graph = g2
+            self._fb_graphs[eng.key] = (eng, g1)
+        except Exception as e:                           # capture is an optimisation, never a requirement
+            import warnings
+            warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
+            torch.cuda.synchronize()
+            self.use_graph = False
+            eng._pending.clear()
+
+    def _step_accumulate(self, eng):
+        """micro-batch: forward/backward (+ graph replay) then gacc += grads; every `accumulate`-th call the
+        all-reduce hook, clip + Adam on the sum, and gacc = 0"""
+        g1 = self._graph_for(eng) if self.use_graph else None
+        if self.use_graph and g1 is None:
+            self._enqueue_fb(eng)                                  # eager warm-up == this call's micro-batch
+            self.gacc.add_(self.model.flat_grads)
+
+            def enqueue():
+                self._enqueue_fb(eng)
+                self.gacc.add_(self.model.flat_grads)
+            self._capture(eng, enqueue)
         elif self.use_graph:
-            self._graph[0].replay()
+            g1.replay()
         else:
             self._enqueue_fb(eng)
             self.gacc.add_(self.model.flat_grads)
@@ -291,8 +298,8 @@ class NativeTrainStep:
             return
         if self.grad_hook is not None:
             self.grad_hook(self.gacc)
-        if self.use_graph and self._graph is not None:
-            self._graph[1].replay()
+        if self.use_graph and self._opt_graph is not None:
+            self._opt_graph.replay()
         else:
             self._optimizer()
         self._micro = 0
@@ -333,7 +340,7 @@ class NativeTrainStep:
                 step = max(step, int(float(st["step"])))
             off += k
         self.d_step.fill_(step)
-        self._graph = None                         # captured scalars (lr, betas) may have changed
+        self._fb_graphs, self._opt_graph = {}, None   # captured scalars (lr, betas) may have changed
 
     def profile_step(self, images, targets, detail=False):
         """One EAGER step with a HIP event pair around every launch (recorded on the launch stream).

@@ -34,13 +34,13 @@ def _ckpt_path(model_name, last_epoch, root="SAVED_CHECKPOINT"):
 
 def load_model_checkpoint(model_name, model, last_epoch, root="SAVED_CHECKPOINT"):
     """reference utils/utils.py:66-73"""
-    checkpoint = torch.load(_ckpt_path(model_name, last_epoch, root), map_location=config.DEVICE, weights_only=False)
+    checkpoint = torch.load(_ckpt_path(model_name, last_epoch, root), map_location=config.DEVICE, weights_only=True)
     model.load_state_dict(checkpoint["state_dict"])
 
 
 def load_optim_checkpoint(model_name, optim, last_epoch, root="SAVED_CHECKPOINT"):
     """reference utils/utils.py:76-82; `optim` is a torch optimizer or a NativeTrainStep"""
-    checkpoint = torch.load(_ckpt_path(model_name, last_epoch, root), map_location=config.DEVICE, weights_only=False)
+    checkpoint = torch.load(_ckpt_path(model_name, last_epoch, root), map_location=config.DEVICE, weights_only=True)
     if hasattr(optim, "load_optimizer_state_dict"):
         optim.load_optimizer_state_dict(checkpoint["optimizer"])
     else:
