@@ -192,6 +192,47 @@ def test_multi_scale_plan_cache_eviction_and_graphs(monkeypatch):
     assert np.linalg.norm(d1 - d2) <= 0.1 * np.linalg.norm(d2), (np.linalg.norm(d1 - d2), np.linalg.norm(d2))
 
 
+def test_config4_inference_1280_slab_path_and_detect():
+    """BASELINE.json configs[4], the detect.py flow (reference detect.py:50-54: model(img) -> cells_to_bboxes -> NMS) at
+    batch 128 @ 1280x1280, bf16 eval. The second conv's input view is 5 GB, so y5m_conv runs it (and every other layer
+    above 2 GiB) in slabs of whole images: the logits of images 0-3 and 124-127 must equal the same images run as one
+    4-image batch each (no slabs, same kernels per layer or not: bf16 tolerance). Then decode + NMS of the MODEL's logits
+    (regime (i): random-init weights, nearly every candidate passes 0.01) for two images: kept index sets and rows
+    bit-exact against the CPU oracle on the very same decoded boxes."""
+    from oracle import loss_ref
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    from yolov5m_amd.utils.bboxes_utils import nms_batched
+    B, S = 128, 1280
+    m = _model("bf16"); m.eval()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.rand((B, 3, S, S), generator=g, device=DEV, dtype=torch.float32)
+    with torch.no_grad():
+        big = [o.clone() for o in m(x)]
+    assert [tuple(o.shape) for o in big] == [(B, 3, S // s, S // s, 85) for s in (8, 16, 32)]
+    assert all(bool(torch.isfinite(o).all()) for o in big)
+    for lo in (0, B - 4):
+        with torch.no_grad():
+            small = m(x[lo:lo + 4].contiguous())
+        for i in range(3):
+            ref, got = small[i].float(), big[i][lo:lo + 4].float()
+            err = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+            assert err < 2e-2, (lo, i, err)
+    anchors = m.head.anchors
+    sel = [0, B - 1]
+    boxes = cells_to_bboxes([o[sel].contiguous() for o in big], anchors, [8, 16, 32], is_pred=True, to_list=False)
+    assert boxes.shape == (2, 100800, 6)
+    bx = boxes.cpu().numpy()
+    for thr, iou in ((0.25, 0.45), (0.01, 0.6)):
+        ref = loss_ref.non_max_suppression(bx, iou, thr, 300)
+        rows, idx, cnt = nms_batched(boxes, iou, thr, 300)
+        rows, idx, cnt = rows.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+        for b in range(2):
+            rr, ri = ref[b]
+            assert cnt[b] == len(ri) and np.array_equal(idx[b, :cnt[b]], ri), (thr, b)
+            assert np.array_equal(rows[b, :cnt[b]].view(np.uint32), rr.view(np.uint32))
+    m._engines.clear()
+
+
 def test_large_batch_first_step_golden(golden):
     """B=16 @ 320x320 (every layer width runs multi-workgroup BN reductions through the SHARED workspaces, the
     pointwise / merged-C3 / multi-tap kernel variants all fire): train-mode logits and ComputeLoss of the first
