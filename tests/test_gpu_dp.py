@@ -17,3 +17,15 @@ def test_rccl_allreduce_between_graphs_single_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_smoke.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "dp smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_dp_two_ranks_gradient_sum_and_identical_parameters():
+    """SURVEY 8e parity for data parallelism, two ranks sharing this GPU over gloo (RCCL refuses two ranks on one
+    device; the collective calls are the same): the exchanged gradient == sum of the single-replica gradients, the
+    bucketed exchange is overlapped with the backward segments (per-segment hipGraphs), parameters stay bit-identical
+    across ranks, and the overlapped schedule lands where the plain one does. tools/dp_parity.py holds the checks."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", Y5M_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tools", "dp_parity.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "dp parity ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])

@@ -21,7 +21,7 @@ step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=True, grad_hook=h
 x = synth_images(4, 320, 320).to("cuda"); t = synth_labels(4, 8).to("cuda")
 losses = [float(step.step(x, t)[0]) for _ in range(6)]
 torch.cuda.synchronize()
-print("losses", [round(v, 3) for v in losses], "allreduce calls", len(calls), "graph", step._graph is not None)
-assert all(v == v for v in losses) and losses[-1] < losses[0] and len(calls) == 6 and step._graph is not None
+print("losses", [round(v, 3) for v in losses], "allreduce calls", len(calls), "graph", step._opt_graph is not None)
+assert all(v == v for v in losses) and losses[-1] < losses[0] and len(calls) == 6 and step._opt_graph is not None
 dist.destroy_process_group()
 print("dp smoke ok")

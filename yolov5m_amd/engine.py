@@ -871,6 +871,44 @@ class Engine:
         run.kind = "join"
         return run
 
+    def join_all(self):
+        """make the current stream wait for every weight gradient still running on the side stream (used where a captured
+        segment of the backward list ends: a capture may not end with forked work outstanding)"""
+        for slot in list(self._pending):
+            torch.cuda.current_stream().wait_event(self._pending.pop(slot))
+
+    def grad_cuts(self, fractions=(0.5, 0.9)):
+        """Cut points of the backward launch list for an overlapped gradient exchange. Returns [(op index k, element
+        offset lo)], ascending in k / descending in lo: after self.bwd[:k] has run (and join_all()), every parameter
+        gradient at flat offset >= lo is final. The backward pass finishes the head first and the stem last while the flat
+        buffer is in model order, so the finished part is a growing SUFFIX of the buffer; a cut is taken at the first unit
+        boundary where that suffix holds at least the given fraction of all gradient elements (most parameters sit in the
+        deep layers, which finish early: half of the elements are final after about a fifth of the backward time)."""
+        base, numel = self.model.flat_grads.data_ptr(), self.model.flat_grads.numel()
+        ranges = []                                          # (lo, hi, op index after which final)
+        for k, name, _addr in self.bwd_marks:
+            P = self.model.pslices[name]
+            for key in ("gw", "gg", "gb"):
+                if key in P:
+                    lo = (P[key].data_ptr() - base) // 4
+                    ranges.append((lo, lo + P[key].numel(), k))
+        ranges.sort()
+        assert ranges[0][0] == 0 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and ranges[-1][1] == numel, \
+            "the unit marks must tile the flat gradient buffer"
+        cuts = []
+        for f in fractions:
+            for k in sorted({r[2] for r in ranges}):
+                lo = numel
+                for r in reversed(ranges):
+                    if r[2] > k:
+                        break
+                    lo = r[0]
+                if numel - lo >= f * numel:
+                    if 0 < lo and (not cuts or (k > cuts[-1][0] and lo < cuts[-1][1])):
+                        cuts.append((k, lo))
+                    break
+        return cuts
+
     def _batch_packs(self):
         """Fold every y5m_pack_weights entry of self.pack into ONE launch over a device job table."""
         L, dt = self.L, self.dtype

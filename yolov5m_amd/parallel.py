@@ -9,12 +9,21 @@ for. Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, point-to-point, no switch
     multiplied by its local batch size, ultralytics_loss.py:120), i.e. exactly the gradient of the
     single-process loss on the concatenated batch up to BatchNorm's per-replica statistics (the
     reference has no SyncBN to match);
-  * NativeTrainStep runs forward+loss+backward as ONE captured hipGraph, then the all-reduce of the whole flat
-    buffer (GradAllReduce.__call__, stream-ordered), then the optimizer graph: at 84.8 MB the exchange is
-    well under a millisecond of a ~31 ms step, so it is not split. `make_buckets` / `launch` / `wait` are the
-    pieces of the bucketed variant (contiguous ranges in BACKWARD order, head first, cut at layer units) for an
-    eager backward that wants to overlap them; they are covered by the gloo tests;
-  * the optimizer then runs identically on every rank (no parameter broadcast after step 0).
+  * the exchange is OVERLAPPED with the backward pass (NativeTrainStep._step_overlapped): the backward launch list is
+    cut where the finished part of the flat buffer -- a growing suffix: the head's gradients are final first, the
+    stem's last -- reaches 50 % and 90 % of the elements (Engine.grad_cuts; most parameters sit in the deep layers, so
+    the first cut comes after about a fifth of the backward time). Each segment is its own captured hipGraph; after a
+    segment is enqueued, GradAllReduce.launch starts the asynchronous SUM all-reduce of the range it finished (on the
+    backend's stream, ordered after the segment) and it runs under the next segment's data / weight gradients; all
+    are waited for before the optimizer graph. Three buckets of ~42 / 34 / 8 MB: few, large messages suit rings that are
+    bound per xGMI link. `overlap=False` (or a plain callable as grad_hook) gives one all-reduce after the backward pass;
+  * the optimizer then runs identically on every rank (no parameter broadcast after step 0). Gradients are SUMMED, and
+    the reference's clip_grad_norm_(10) (train.py:118) is applied to that sum: with W ranks the clip engages at 1/W of
+    the per-replica gradient norm -- the same as the single-process recipe on the W-times larger batch, whose loss is
+    also a sum over images (ultralytics_loss.py:120). Rescale max_norm by W to keep the per-replica threshold instead;
+  * tools/dp_parity.py (tests/test_gpu_dp.py, two ranks): exchanged gradient == sum of the single-replica gradients,
+    parameters bit-identical across ranks after captured steps, overlapped == plain schedule. No scaling curve has been
+    measured by this build (one GPU per box): the driver's SCALE run is the first multi-GPU execution.
 Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests). `Y5M_DIST_BACKEND=gloo`
 forces gloo on GPU tensors too: with LOCAL_RANK folded onto the visible devices this lets a 1-GPU box run the
 whole multi-process flow (RCCL itself refuses two ranks on one device).
@@ -95,6 +104,7 @@ def broadcast_parameters(model, src=0, group=None):
     if getattr(model, "flat_params", None) is not None:
         dist.broadcast(model.flat_params, src=src, group=group)
         dist.broadcast(model._flat_stats, src=src, group=group)
+        dist.broadcast(model._nbt, src=src, group=group)       # BatchNorm2d.num_batches_tracked
     else:
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=src, group=group)

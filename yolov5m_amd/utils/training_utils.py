@@ -97,7 +97,7 @@ class NativeTrainStep:
     all-reduce plugs in here)."""
 
     def __init__(self, model, loss_fn, lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY, max_norm=10.0,
-                 betas=(0.9, 0.999), eps=1e-8, nt_max=1024, use_graph=False, grad_hook=None, accumulate=1):
+                 betas=(0.9, 0.999), eps=1e-8, nt_max=1024, use_graph=False, grad_hook=None, accumulate=1, overlap=True):
         """accumulate: micro-batches per optimizer step (reference train_loop :87-89, `nbs=64 / batch_size`):
         gradients of `accumulate` consecutive step() calls are SUMMED (the loss is already scaled by the batch
         size, ultralytics_loss.py:118) and clip + Adam run on the sum; flush() forces the step at an epoch end."""
@@ -108,6 +108,7 @@ class NativeTrainStep:
         self.lr, self.wd, self.max_norm, self.betas, self.eps = lr, weight_decay, max_norm, betas, eps
         self.nt_max = nt_max
         self.use_graph = use_graph
+        self.overlap = overlap and accumulate == 1          # bucketed exchange under the backward pass (grad_hook with .launch/.wait)
         self.grad_hook = grad_hook
         model.train()
         model.flatten_parameters()
@@ -132,7 +133,7 @@ class NativeTrainStep:
             self.gacc = torch.zeros(n, dtype=torch.float32, device=dev)
 
     # forward + build-targets + loss (+ d loss / d logits) + backward: everything before the optimizer
-    def _enqueue_fb(self, eng, timeline=None):
+    def _enqueue_fb(self, eng, timeline=None, bwd_upto=None):
         from ..ultralytics_loss import _Workspace
         L = _lib.lib()
         lf = self.loss_fn
@@ -169,7 +170,9 @@ class NativeTrainStep:
         loss_ops.kind = "loss"
         eng._run([(loss_ops, ())], timeline)
         self.loss_out = ws.loss_out
-        eng._run(eng.bwd, timeline)
+        eng._run(eng.bwd if bwd_upto is None else eng.bwd[:bwd_upto], timeline)
+        if bwd_upto is not None:
+            eng.join_all()
 
     def _optimizer(self, timeline=None):
         L = _lib.lib()
@@ -219,6 +222,8 @@ class NativeTrainStep:
         self.model._nbt += 1
         if self.accumulate > 1:
             return self._step_accumulate(eng)
+        if self.overlap and hasattr(self.grad_hook, "launch"):
+            return self._step_overlapped(eng)
         if not self.use_graph:
             self._enqueue_fb(eng)
             if self.grad_hook is not None:
@@ -238,6 +243,78 @@ class NativeTrainStep:
         if self.grad_hook is not None:
             self.grad_hook(self.model.flat_grads)
         self._opt_graph.replay()
+        return self.loss_out
+
+    def _step_overlapped(self, eng):
+        """Data-parallel step with the gradient exchange overlapped with the backward pass (north_star: "RCCL all-reduce of
+        gradients over xGMI overlapped with the backward convs"). The backward launch list is cut at Engine.grad_cuts()
+        into segments; after a segment has been enqueued (eager, or replayed as its own hipGraph), the all-reduce of the
+        flat-buffer range that segment finished is launched asynchronously (GradAllReduce.launch: the collective runs on
+        the backend's own stream, ordered after everything enqueued so far) and proceeds under the next segment's data and
+        weight gradients. Buckets are few and large -- xGMI rings are per-link bound -- and in backward order, head first.
+        All exchanges are waited for right before the optimizer."""
+        hook, flat = self.grad_hook, self.model.flat_grads
+        cuts = getattr(eng, "_cuts", None)
+        if cuts is None:
+            cuts = eng._cuts = eng.grad_cuts()
+        n = flat.numel()
+        ks = [k for k, _ in cuts] + [len(eng.bwd)]
+        los = [lo for _, lo in cuts] + [0]
+        his = [n] + los[:-1]
+
+        def seg(i):                                        # enqueue segment i of forward+loss+backward
+            if i == 0:
+                self._enqueue_fb(eng, bwd_upto=ks[0])
+            else:
+                eng._run(eng.bwd[ks[i - 1]:ks[i]])
+                if i < len(ks) - 1:
+                    eng.join_all()
+
+        graphs = None
+        if self.use_graph:
+            ent = self._fb_graphs.get(eng.key)
+            for k in [k for k, e in self._fb_graphs.items() if e[0].released]:
+                del self._fb_graphs[k]
+            graphs = ent[1] if ent is not None and ent[0] is eng and self._opt_graph is not None else None
+        if self.use_graph and graphs is None:
+            # eager warm-up step (this call's step), then capture one graph per segment
+            for i in range(len(ks)):
+                seg(i)
+                hook.launch(flat, los[i], his[i])
+            hook.wait()
+            self._optimizer()
+            torch.cuda.synchronize()
+            try:
+                gs = []
+                for i in range(len(ks)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        seg(i)
+                    gs.append(g)
+                if self._opt_graph is None:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                        self._optimizer()
+                    self._opt_graph = g2
+                self._fb_graphs[eng.key] = (eng, gs)
+            except Exception as e:
+                import warnings
+                warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
+                torch.cuda.synchronize()
+                self.use_graph = False
+                eng._pending.clear()
+            return self.loss_out
+        for i in range(len(ks)):
+            if graphs is not None:
+                graphs[i].replay()
+            else:
+                seg(i)
+            hook.launch(flat, los[i], his[i])
+        hook.wait()
+        if graphs is not None:
+            self._opt_graph.replay()
+        else:
+            self._optimizer()
         return self.loss_out
 
     def _graph_for(self, eng):
