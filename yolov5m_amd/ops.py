@@ -120,7 +120,7 @@ def conv_forward_stats(x, w, stride, pad, dtype="f32"):
 
 def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=None):
     """dy (B,Cout,Ho,Wo), w (Cout,Cin,k,k) -> dx (B,Cin,H,W): autograd of conv2d wrt its input.
-    init (B,Cin,H,W): accumulate the gradient onto it (the engine's fan-out accumulation; stride 1 only).
+    init (B,Cin,H,W): accumulate the gradient onto it (the engine's fan-out accumulation).
     src  (B,Cin,H,W): dx = src + gradient with src read from its OWN tensor (the fused residual gradient).
     bn   [(y (B,C1,H,W), scale (C1,), shift (C1,)), (y2, scale2, shift2) or None]: dx is the gradient of
          z = silu(y*scale+shift) for channels [0,C1) (and of the second producer for the rest); also returns the
@@ -132,7 +132,6 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=N
     H, W = in_hw
     dyn = to_nhwc(dy, tdt)
     dx = torch.zeros((B, H, W, Cin), dtype=tdt, device=dy.device) if init is None else to_nhwc(init, tdt)
-    assert init is None or stride == 1
     srcn = to_nhwc(src, tdt) if src is not None else None
     if src is not None:
         dx.fill_(7.0)                # must be overwritten, not accumulated
