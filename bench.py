@@ -35,24 +35,24 @@ FWD_GFLOP_PER_IMAGE_640 = 48.872
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the conv kernels from the committed PMC summary (profiles/rNN_pmc_bench.json,
-    produced by tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, gfx950 x2 on fetch).
-    bench.py cannot run rocprofv3 on itself, so this is the last committed measurement of the same workload
-    (B=64 @ 640x640) or None."""
+    """(HBM bytes per launch of the conv kernels, where the number comes from). bench.py cannot run rocprofv3 on itself
+    inside its timed process, so this is an OFFLINE figure: the last committed PMC summary of the same workload
+    (profiles/rNN_pmc_bench.json from tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, gfx950 x2 on
+    fetch, B=64 @ 640x640, --no-graph, first-touch fills included). (None, reason) when there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench.json")))
     if not files:
-        return None
+        return None, "no profiles/r*_pmc_bench.json committed"
     try:
         k = json.load(open(files[-1]))["kernels"]
         tot = n = 0.0
-        for name in ("conv_igemm_kernel", "conv_pw_kernel"):
+        for name in ("conv_igemm_kernel", "conv_pw_kernel", "conv_halo_kernel", "conv_igemm_multi_kernel"):
             if name in k:
                 tot += k[name]["hbm_bytes_per_launch"] * k[name]["launches"]
                 n += k[name]["launches"]
-        return round(tot / n) if n else None
-    except Exception:
-        return None
+        return (round(tot / n) if n else None), f"offline: {os.path.relpath(files[-1], ROOT)} (average over the conv kernels' launches)"
+    except Exception as e:
+        return None, f"unreadable {files[-1]}: {e}"
 
 
 def cpu_baseline(B=4, size=640, steps=3):
@@ -297,8 +297,12 @@ def main():
         fams = {}
         cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
         esz = 2 if args.dtype == "bf16" else 4
+        kernels = {}
         for _ in range(2):
-            fam, convs = step.profile_step(images, targets, detail=True)
+            fam, convs, kern = step.profile_step(images, targets, detail="kernels")
+            for name, ms_, fl in kern:
+                k = kernels.setdefault(name, [0.0, 0.0, 0])
+                k[0] += ms_; k[1] += fl; k[2] += 1
             for k, (m_, n_) in fam.items():
                 a, b = fams.get(k, (0.0, 0))
                 fams[k] = (a + m_, b + n_)
@@ -317,13 +321,26 @@ def main():
         conv_n //= 2
         achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
         wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
+        # headline = the ONE kernel instantiation with the largest share of the step (by summed launch time, HIP events on
+        # the launching stream, side stream serialised); the conv family and the per-kernel table sit beside it
+        ranked = sorted(kernels.items(), key=lambda kv: -kv[1][0])
+        dom_name, (dom_ms, dom_fl, dom_n) = ranked[0]
+        dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         out["roofline"] = {
-            "bound": "mfma", "kernel": "y5m_conv: conv_igemm_kernel<bf16> + conv_pw_kernel (forward conv + data gradient, all "
-                                       "launches of one step)",
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
-            "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
-            "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1),
+            "bound": "mfma", "kernel": dom_name,
+            "achieved": round(dom_tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(dom_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "launches_per_step": dom_n // 2, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
+            "algorithmic_gflop_per_launch": round(dom_fl / max(dom_n, 1) / 1e9, 2),
+            "share_of_step_ms": round(dom_ms / 2, 3),
+            "by_kernel": [{"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
+                           "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                           "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)} for n_, v in ranked[:8]],
+            "conv_family": {"what": "forward conv + data gradient, all y5m_conv launches of one step",
+                            "achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                            "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
+                            "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1)},
             "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
             "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
             # the same launches split by what bounds them: k x k taps (MFMA) vs 1x1 (HBM: every input and output

@@ -218,6 +218,10 @@ int y5m_conv(const y5m_conv_args* args, int dtype, void* stream);
  * Any other set of problems is run as n y5m_conv calls. */
 int y5m_conv_multi(const y5m_conv_args* args, int n, int dtype, void* stream);
 /* 1 when y5m_conv would run this launch on the pointwise streaming kernel (HBM-bound), 0 for the tiled one */
+/* the kernel instantiation y5m_conv / y5m_conv_multi / y5m_wgrad would launch for these arguments, as text
+ * ("conv_halo_kernel<6,0>"), nothing is launched: profilers and bench.py attribute times and rooflines with it */
+int y5m_conv_kernel_name(const y5m_conv_args* args, int dtype, char* buf, int n);
+int y5m_conv_multi_kernel_name(const y5m_conv_args* args, int cnt, int dtype, char* buf, int n);
 int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype);
 /* 1 when y5m_conv would run this launch on the persistent 3x3 halo-patch kernel (bf16, stride 1, >= 64 input channels,
  * output channels a multiple of 96, image width such that two input patches fit the LDS) */
@@ -245,6 +249,7 @@ typedef struct {
     int32_t pad_;
 } y5m_wgrad_args;
 int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
+int y5m_wgrad_kernel_name(const y5m_wgrad_args* args, int dtype, char* buf, int n);   /* see y5m_conv_kernel_name */
 /* the number of pixel ranges (= slices written in non-atomic mode) y5m_wgrad will use for these arguments */
 int y5m_wgrad_slices(const y5m_wgrad_args* args, int dtype);
 

@@ -112,6 +112,9 @@ _SIGS = {
     "y5m_conv_tile_n": (c_int, [c_int]),
     "y5m_conv_is_pointwise": (c_int, [c_void_p, c_int]),
     "y5m_conv_stats_rows": (c_int, [c_void_p, c_int]),
+    "y5m_conv_kernel_name": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "y5m_conv_multi_kernel_name": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
+    "y5m_wgrad_kernel_name": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "y5m_conv_is_halo": (c_int, [c_void_p, c_int]),
     "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_conv_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),

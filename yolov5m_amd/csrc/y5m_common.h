@@ -24,6 +24,18 @@ extern "C" void y5m_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// "which kernel would this call launch?" (y5m_conv_kernel_name / y5m_wgrad_kernel_name): the dispatch runs as usual, the
+// launcher writes the instantiation it chose here instead of launching it
+extern thread_local int y5m_name_only;
+extern thread_local char y5m_name_buf[192];
+#define Y5M_NAME_ONLY(RET, ...)                                                      \
+    do {                                                                             \
+        if (y5m_name_only) {                                                         \
+            snprintf(y5m_name_buf, sizeof(y5m_name_buf), __VA_ARGS__);               \
+            return RET;                                                              \
+        }                                                                            \
+    } while (0)
+
 static inline hipStream_t y5m_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t y5m_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

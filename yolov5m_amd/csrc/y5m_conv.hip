@@ -448,6 +448,7 @@ static int launch_conv_multi(ConvMulti& MP, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
+    Y5M_NAME_ONLY(Y5M_OK, "conv_igemm_multi_kernel<%s,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WM, WN, MF, NF);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * MP.n)), dim3(WM * WN * 64), lds, st, MP);
     Y5M_CHECK_LAUNCH("conv_igemm_multi_kernel");
     return Y5M_OK;
@@ -465,6 +466,7 @@ static int launch_conv_db(ConvParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
+    Y5M_NAME_ONLY(Y5M_OK, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WM, WN, MF, NF, (int)DB, (int)BNR);
     hipLaunchKernelGGL(kern, dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(WM * WN * 64), lds, st, P);
     Y5M_CHECK_LAUNCH("conv_igemm_kernel");
     return Y5M_OK;
@@ -490,6 +492,23 @@ static int launch_conv(ConvParams& P, hipStream_t st) {
     }
     if (P.Kp / BK <= g_sbuf_kt) return launch_conv_db<T, WM, WN, MF, NF, false>(P, st);
     return launch_conv_db<T, WM, WN, MF, NF, true>(P, st);
+}
+
+static int name_of(int rc, char* buf, int n) {
+    y5m_name_only = 0;
+    if (rc != Y5M_OK) return rc;
+    snprintf(buf, (size_t)n, "%s", y5m_name_buf);
+    return Y5M_OK;
+}
+extern "C" int y5m_conv_kernel_name(const y5m_conv_args* args, int dtype, char* buf, int n) {
+    y5m_name_only = 1;
+    y5m_name_buf[0] = 0;
+    return name_of(y5m_conv(args, dtype, nullptr), buf, n);
+}
+extern "C" int y5m_conv_multi_kernel_name(const y5m_conv_args* args, int cnt, int dtype, char* buf, int n) {
+    y5m_name_only = 1;
+    y5m_name_buf[0] = 0;
+    return name_of(y5m_conv_multi(args, cnt, dtype, nullptr), buf, n);
 }
 
 extern "C" int y5m_conv_tile_n(int N) {

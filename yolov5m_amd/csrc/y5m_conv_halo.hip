@@ -565,6 +565,7 @@ static int launch_halo(const ConvParams& P, const HaloArgs& G, hipStream_t st) {
         if (g_halo_cus <= 0) g_halo_cus = 256;
     }
     const int grid = G.total < g_halo_cus ? G.total : g_halo_cus;
+    Y5M_NAME_ONLY(Y5M_OK, "conv_halo_kernel<%d,%d>", NF, EPI);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(HL_THREADS), lds, st, P, G);
     Y5M_CHECK_LAUNCH("conv_halo_kernel");
     return Y5M_OK;

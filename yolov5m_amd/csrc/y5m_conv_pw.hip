@@ -319,6 +319,7 @@ static int launch_pw(const ConvParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
+    Y5M_NAME_ONLY(1, "conv_pw_kernel<%d,%d,%d,%d,%d,%d>", NCF, KS, EPI, (int)OLD, (int)BNR, TAPC);
     hipLaunchKernelGGL(kern, dim3((unsigned)(sblocks * nchunks)), dim3(PW_THREADS), lds, st, P, nchunks, nstreams, ngroups, stat_rows);
     Y5M_CHECK_LAUNCH("conv_pw_kernel");
     return 1;

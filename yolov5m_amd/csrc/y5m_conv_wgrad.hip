@@ -403,6 +403,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr = true;
     }
+    Y5M_NAME_ONLY(Y5M_OK, "wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WN, WC, WK, CFR, TPB, NFR, (int)use_sb);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
     Y5M_CHECK_LAUNCH("wgrad_kernel");
     return Y5M_OK;
@@ -432,6 +433,16 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     if (big == 3 && P.N % 192 == 0) return launch_wgrad<T, 4, 2, 1, 3, 1, 3>(P, st);        // 192 x 96, 8 waves of 48 x 48
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
+}
+
+extern "C" int y5m_wgrad_kernel_name(const y5m_wgrad_args* args, int dtype, char* buf, int n) {
+    y5m_name_only = 1;
+    y5m_name_buf[0] = 0;
+    const int rc = y5m_wgrad(args, dtype, nullptr);
+    y5m_name_only = 0;
+    if (rc != Y5M_OK) return rc;
+    snprintf(buf, (size_t)n, "%s", y5m_name_buf);
+    return Y5M_OK;
 }
 
 extern "C" int y5m_wgrad_slices(const y5m_wgrad_args* args, int dtype) {

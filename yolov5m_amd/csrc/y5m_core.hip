@@ -4,6 +4,8 @@
 #include <string.h>
 
 static thread_local char g_err[512] = "";
+thread_local int y5m_name_only = 0;
+thread_local char y5m_name_buf[192] = "";
 
 extern "C" void y5m_set_error(const char* fmt, ...) {
     va_list ap;

@@ -322,7 +322,7 @@ class Engine:
             # wgrad is HBM/atomic-bound, dgrad MFMA-bound, and neither fills the chip alone
             mode = 2 if lay.stem else 0
             ops.append((self._side_op(self._wgrad_ops(lay, wa, [(0, lay.cout, lay.cin_real, lay.k, mode, P["gw"].data_ptr())]),
-                                      slot), ()))
+                                      slot, wa), ()))
             self._grad_done.append((lay.name, P["gw"].data_ptr()))
             # data gradient
             if need_dx:
@@ -586,7 +586,7 @@ class Engine:
             wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
             wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = K, N2, M, N2, K, 0
             fs = self._wgrad_ops(halves[0][0], wa, [(lay.off, cout, K, 1, 0, P["gw"].data_ptr()) for lay, P in halves])
-            ops.append((self._side_op(fs, slot), ()))
+            ops.append((self._side_op(fs, slot, wa), ()))
             for lay, P in halves:
                 self._grad_done.append((lay.name, P["gw"].data_ptr()))
             if need_dx:
@@ -719,7 +719,7 @@ class Engine:
                 wa.th, wa.tw, wa.dh0, wa.dhs, wa.dw0, wa.dws = 1, 1, 0, 1, 0, 1
                 wa.C, wa.N, wa.M, wa.lddy, wa.lddw, wa.ksplit = x.C, ldp, M, ldp, x.C, 0
                 lay.wgrad_args = wa
-                ops.append((self._side_op(self._wgrad_ops(lay, wa, [(0, N, x.C, 1, 0, P["gw"].data_ptr())]), slot), ()))
+                ops.append((self._side_op(self._wgrad_ops(lay, wa, [(0, N, x.C, 1, 0, P["gw"].data_ptr())]), slot, wa), ()))
                 self._grad_done.append((lay.name, P["gw"].data_ptr()))
                 self._written(x)
                 acc = 1 if x.gw else 0
@@ -840,7 +840,7 @@ class Engine:
             self._side = torch.cuda.Stream()
         return self._side
 
-    def _side_op(self, fns, slot):
+    def _side_op(self, fns, slot, wa=None):
         """Run `fns` on the side stream, ordered after everything enqueued so far on the current stream
         (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
         hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
@@ -861,6 +861,7 @@ class Engine:
                 done.record(side)
             self._pending[slot] = done
         run.kind = "wgrad"
+        run.wa = wa                     # the y5m_wgrad_args of this launch (bench.py: per-kernel roofline)
         return run
 
     def _join_op(self, slot):

@@ -452,4 +452,28 @@ class NativeTrainStep:
                 convs.extend((ms * a.K / tot, a) for a in parts)
             elif d:
                 convs.append((e0.elapsed_time(e1), d[0]))
-        return fam, convs
+        if detail != "kernels":
+            return fam, convs
+        # per-kernel view: (kernel instantiation name, ms, algorithmic flop) of every conv / data-gradient / weight-gradient
+        # launch (y5m_*_kernel_name asks the library which instantiation it dispatches to)
+        L = _lib.lib()
+        buf = ctypes.create_string_buffer(192)
+        kern = []
+        for (kind, e0, e1), item in zip(tl, items):
+            if item is None:
+                continue
+            ms = e0.elapsed_time(e1)
+            if kind == "conv_igemm":
+                d = getattr(item[0], "__defaults__", None)
+                if d and hasattr(d[0], "_length_"):
+                    arr = d[0]
+                    _lib.check(L.y5m_conv_multi_kernel_name(arr, len(arr), eng.dtype, buf, 192), "kernel_name")
+                    kern.append((buf.value.decode(), ms, sum(2.0 * a.M * a.N * a.K for a in arr)))
+                elif d:
+                    _lib.check(L.y5m_conv_kernel_name(ctypes.byref(d[0]), eng.dtype, buf, 192), "kernel_name")
+                    kern.append((buf.value.decode(), ms, 2.0 * d[0].M * d[0].N * d[0].K))
+            elif kind == "wgrad" and getattr(item[0], "wa", None) is not None:
+                wa = item[0].wa
+                _lib.check(L.y5m_wgrad_kernel_name(ctypes.byref(wa), eng.dtype, buf, 192), "kernel_name")
+                kern.append((buf.value.decode() + " (+ unpack)", ms, 2.0 * wa.M * wa.N * wa.th * wa.tw * wa.C))
+        return fam, convs, kern
