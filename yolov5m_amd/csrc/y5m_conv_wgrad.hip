@@ -15,6 +15,12 @@
 // tile is [pixel][TPB x CBLK "virtual channels"] (an im2col slice built by the loader, every 16-byte chunk
 // with its own tap offset and bounds test), so dY is read once per TPB taps and a wave gets 3 x 9 MFMAs per
 // 32-pixel step instead of 3 x 1 (stem) or 3 x 3.
+// Tried and removed (round 2): a "row-of-taps" variant for the 3x3 layers -- one 96 x 96 block computes the three
+// horizontal taps from ONE staged dY chunk and ONE X chunk (+ 2 halo rows) in a zero-padded raster, 108 accumulator
+// registers per wave, 2.2x fewer staged bytes per MFMA and dY / X leaving L2 three instead of nine times. Bit-for-bit
+// correct, but 545-560 TFLOP/s isolated against 586 for this kernel on 192 -> 192 @ 40x40 (B = 64), and 28.37 vs 27.93
+// ms/step inside the train step: with three 4-wave blocks per CU it spent 49 % of its wave cycles in s_waitcnt (PMC
+// SQ_WAIT_ANY), i.e. it is bound by the latency of its one-chunk-deep operand prefetch, not by the LDS traffic it saves.
 #include "y5m_conv.h"
 #include <stdlib.h>
 

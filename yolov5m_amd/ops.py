@@ -13,6 +13,7 @@ from ._lib import ConvArgs, WgradArgs, EPI_DGRAD, EPI_AFFINE_ACT, EPI_RAW_STATS,
 _DT = {"f32": (F32, torch.float32, 4, 32), "bf16": (BF16, torch.bfloat16, 8, 64)}
 
 
+LAST_WGRAD_KERNEL = None
 LAST_KERNEL = None      # which kernel family the most recent y5m_conv launch of this module took (tests assert on it)
 
 
@@ -206,6 +207,10 @@ def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0, slices=False):
     a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
     a.C, a.N, a.M, a.lddy, a.lddw, a.ksplit = Cin, Cout, B * Ho * Wo, Cout, k * k * Cin, ksplit
     out = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=dy.device)
+    global LAST_WGRAD_KERNEL
+    _buf = ctypes.create_string_buffer(192)
+    _lib.check(L.y5m_wgrad_kernel_name(ctypes.byref(a), dt, _buf, 192), "y5m_wgrad_kernel_name")
+    LAST_WGRAD_KERNEL = _buf.value.decode()
     if slices:
         a.slices_cap = 4096
         ns = L.y5m_wgrad_slices(ctypes.byref(a), dt)
