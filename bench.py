@@ -34,23 +34,29 @@ PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s (this box's 
 FWD_GFLOP_PER_IMAGE_640 = 48.872
 
 
-def pmc_traffic():
-    """(HBM bytes per launch of the conv kernels, where the number comes from). bench.py cannot run rocprofv3 on itself
-    inside its timed process, so this is an OFFLINE figure: the last committed PMC summary of the same workload
-    (profiles/rNN_pmc_bench.json from tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, gfx950 x2 on
-    fetch, B=64 @ 640x640, --no-graph, first-touch fills included). (None, reason) when there is none."""
+def pmc_traffic(kernel=None):
+    """(HBM bytes per launch, where the number comes from) for the kernel the roofline headline names (all template
+    instances of that kernel, e.g. every wgrad_kernel<...> launch of the step; the PMC summary is keyed by the bare kernel
+    name), or averaged over the conv kernels when no kernel is given / the summary does not hold it. bench.py cannot run
+    rocprofv3 on itself inside its timed process, so this is an OFFLINE figure: the last committed PMC summary of the same
+    workload (profiles/rNN_pmc_bench.json from tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, KiB units,
+    gfx950 x2 on fetch, B=64 @ 640x640, --no-graph, first-touch fills included). (None, reason) when there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench.json")))
     if not files:
         return None, "no profiles/r*_pmc_bench.json committed"
+    rel = os.path.relpath(files[-1], ROOT)
     try:
         k = json.load(open(files[-1]))["kernels"]
+        base = (kernel or "").split("<")[0].strip()
+        if base in k:
+            return round(k[base]["hbm_bytes_per_launch"]), f"offline: {rel} (all {base} launches of the step)"
         tot = n = 0.0
         for name in ("conv_igemm_kernel", "conv_pw_kernel", "conv_halo_kernel", "conv_igemm_multi_kernel"):
             if name in k:
                 tot += k[name]["hbm_bytes_per_launch"] * k[name]["launches"]
                 n += k[name]["launches"]
-        return (round(tot / n) if n else None), f"offline: {os.path.relpath(files[-1], ROOT)} (average over the conv kernels' launches)"
+        return (round(tot / n) if n else None), f"offline: {rel} (average over the conv kernels' launches)"
     except Exception as e:
         return None, f"unreadable {files[-1]}: {e}"
 
@@ -326,7 +332,7 @@ def main():
         ranked = sorted(kernels.items(), key=lambda kv: -kv[1][0])
         dom_name, (dom_ms, dom_fl, dom_n) = ranked[0]
         dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(dom_name)
         out["roofline"] = {
             "bound": "mfma", "kernel": dom_name,
             "achieved": round(dom_tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
