@@ -377,6 +377,35 @@ def test_multi_scale_plan_cache_eviction_and_graphs(monkeypatch):
     assert np.linalg.norm(d1 - d2) <= 0.1 * np.linalg.norm(d2), (np.linalg.norm(d1 - d2), np.linalg.norm(d2))
 
 
+def test_multi_scale_plan_cache_is_bounded_by_memory(monkeypatch):
+    """the default plan cache keeps every size resident while the plans fit the HBM budget (no rebuild when multi_scale
+    comes back to a size), and a budget smaller than one plan keeps exactly the current one (Y5M_ENGINE_CACHE_GB)."""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    sizes = [(64, 64), (64, 96), (96, 96), (64, 64), (96, 96), (64, 96)]
+    batches = [(synth_images(2, h, w, seed=f"mb{i}").to(DEV), synth_labels(2, 4, seed=f"mbl{i}")) for i, (h, w) in enumerate(sizes)]
+    monkeypatch.delenv("Y5M_ENGINE_CACHE", raising=False)
+    monkeypatch.delenv("Y5M_ENGINE_CACHE_GB", raising=False)
+    m = _model("f32"); m.train()
+    step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=True)
+    seen = {}
+    for (h, w), (x, t) in zip(sizes, batches):
+        assert np.isfinite(float(step.step(x, t)[0]))
+        eng = next(reversed(m._engines.values()))
+        assert seen.setdefault((h, w), eng) is eng and not eng.released and eng.nbytes > 0
+    assert len(m._engines) == 3
+    monkeypatch.setenv("Y5M_ENGINE_CACHE_GB", "0.000001")
+    m = _model("f32"); m.train()
+    step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=True)
+    prev = None
+    for x, t in batches[:4]:
+        assert np.isfinite(float(step.step(x, t)[0]))
+        assert len(m._engines) == 1
+        eng = next(iter(m._engines.values()))
+        assert prev is None or prev.released
+        prev = eng
+
+
 def test_config4_inference_1280_slab_path_and_detect():
     """BASELINE.json configs[4], the detect.py flow (reference detect.py:50-54: model(img) -> cells_to_bboxes -> NMS) at
     batch 128 @ 1280x1280, bf16 eval. The second conv's input view is 5 GB, so y5m_conv runs it (and every other layer

@@ -227,15 +227,30 @@ class YOLOV5m(nn.Module):
         key = (B, H, W, dt, self.training)
         eng = self._engines.pop(key, None)
         if eng is None:
-            # bound the resident plans (multi-scale training varies H, W; one training plan at B=64 / 640^2 holds ~40 GB):
-            # least-recently-used eviction with an explicit release, so the evicted plan's HBM is free BEFORE the new
-            # one allocates (a plan is a reference cycle -- its launch closures capture it -- and would otherwise live
-            # until the cyclic GC runs) and a captured graph can never be replayed on freed buffers (Engine.released)
-            cap = max(1, int(os.environ.get("Y5M_ENGINE_CACHE", "4")))
-            while len(self._engines) >= cap:
+            # Resident plans are bounded by HBM, not by a small count: multi_scale training (reference
+            # utils/training_utils.py:11-28) draws one of 11 sizes (320..640 step 32) per batch, and a plan that is evicted
+            # and rebuilt costs seconds (allocation + graph capture) against a 30 ms step. One training plan at B=64 /
+            # 640^2 holds ~40 GB and the footprint scales with B*H*W, so the plans of ALL sizes up to 576 (~180 GB) stay
+            # resident in the default budget (60 % of the device's memory; Y5M_ENGINE_CACHE_GB) and only the two largest
+            # take turns. Least-recently-used eviction with an explicit release, so the evicted plan's HBM is free BEFORE
+            # the new one allocates (a plan is a reference cycle -- its launch closures capture it -- and would otherwise
+            # live until the cyclic GC runs) and a captured graph can never be replayed on freed buffers (Engine.released).
+            # Y5M_ENGINE_CACHE caps the COUNT (default 16).
+            cap = max(1, int(os.environ.get("Y5M_ENGINE_CACHE", "16")))
+            gb = float(os.environ.get("Y5M_ENGINE_CACHE_GB", "0"))
+            budget = gb * 2**30 if gb > 0 else 0.6 * torch.cuda.get_device_properties(x.device).total_memory
+            per_px = max((e.nbytes / max(e.key[0] * e.key[1] * e.key[2], 1) for e in self._engines.values()
+                          if e.key[3:] == key[3:]), default=0.0)
+            need = per_px * B * H * W                     # estimate from a resident plan of the same dtype / mode
+            while self._engines and (len(self._engines) >= cap or
+                                     sum(e.nbytes for e in self._engines.values()) + need > budget):
                 self._engines.pop(next(iter(self._engines))).release()
+            m0 = torch.cuda.memory_allocated(x.device)
             eng = Engine(self, B, H, W, dtype=dt, training=self.training)
             eng.key = key
+            eng.nbytes = max(torch.cuda.memory_allocated(x.device) - m0, 0)
+            while self._engines and sum(e.nbytes for e in self._engines.values()) + eng.nbytes > budget:
+                self._engines.pop(next(iter(self._engines))).release()
         self._engines[key] = eng               # (re-)insert at the most-recently-used end
         return eng
 
