@@ -349,7 +349,7 @@ int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* owner, const 
 size_t y5m_adam_workspace_bytes(void);
 int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes, void* stream);
 int y5m_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm, float max_norm,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_step,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, const int32_t* d_step,
                   void* stream);
 
 #ifdef __cplusplus

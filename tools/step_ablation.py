@@ -37,3 +37,13 @@ for _ in range(20):
     step.step(images, targets)
 torch.cuda.synchronize()
 print(f"stubbed={','.join(names) or 'none':60s} {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms/step", flush=True)
+if os.environ.get("PER_STEP"):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(61)]
+    evs[0].record()
+    for i in range(60):
+        step.step(images, targets)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ts = [evs[i].elapsed_time(evs[i + 1]) for i in range(60)]
+    print("per-step ms:", " ".join(f"{t:.2f}" for t in ts))
+    print(f"min {min(ts):.3f} median {sorted(ts)[30]:.3f} mean {sum(ts)/60:.3f} max {max(ts):.3f}")

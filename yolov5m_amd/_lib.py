@@ -158,8 +158,8 @@ _SIGS = {
     "y5m_compute_loss_owner_ptrs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "y5m_adam_workspace_bytes": (c_size_t, []),
     "y5m_grad_norm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "y5m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
-                              c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "y5m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_double,
+                              c_double, c_double, c_double, c_double, c_void_p, c_void_p]),
 }
 
 _lib = None

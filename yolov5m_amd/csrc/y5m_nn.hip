@@ -1192,44 +1192,53 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]);   // total L2 norm
 }
+// omb1 / omb2 = 1 - beta, rounded ONCE from the double-precision difference as torch.optim.Adam does (python floats:
+// 1 - 0.999 = 0.001 -> f32); 1.0f - 0.999f would be 1.3e-5 off, a systematic scale error of the second moment
 __device__ __forceinline__ void adam_one(float& pw, float g, float& mi, float& vi, float clip, float lr_bc1, float b1, float b2,
-                                         float eps, float wd, float bc2_sqrt) {
+                                         float omb1, float omb2, float eps, float wd, float bc2_sqrt) {
     float gi = g * clip;
     gi = gi + wd * pw;                            // Adam(weight_decay=): L2 added to the gradient
-    mi = b1 * mi + (1.0f - b1) * gi;
-    vi = b2 * vi + (1.0f - b2) * gi * gi;
+    mi = b1 * mi + omb1 * gi;
+    vi = b2 * vi + omb2 * gi * gi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pw = pw - lr_bc1 * (mi / denom);
 }
 // 4 parameters per thread (16-byte accesses on all 7 streams); the tail is handled by the last threads one by one
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            int64_t n, const float* __restrict__ gnorm, float max_norm, float lr, float b1, float b2,
+                            int64_t n, const float* __restrict__ gnorm, float max_norm, double lr, double b1d, double b2d,
                             float eps, float wd, const int32_t* __restrict__ d_step) {
+    // the step counter lives on the device so a captured hipGraph replays with the right bias correction; the corrections
+    // are evaluated in double by one thread per block, exactly the scalars torch.optim.Adam computes on the host
+    // (step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t)) and then rounds to f32
+    __shared__ float s_bc[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)d_step[0];
+        s_bc[0] = (float)(lr / (1.0 - pow(b1d, t)));
+        s_bc[1] = (float)sqrt(1.0 - pow(b2d, t));
+    }
+    __syncthreads();
     const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n4 = n >> 2;
     if (i4 > n4) return;
-    // the step counter lives on the device so a captured hipGraph replays with the right bias correction
-    const float stepf = (float)d_step[0];
-    const float bc1 = 1.0f - powf(b1, stepf);
-    const float bc2_sqrt = sqrtf(1.0f - powf(b2, stepf));
+    const float lr_bc1 = s_bc[0], bc2_sqrt = s_bc[1];
+    const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
     float clip = 1.0f;
     if (max_norm > 0.f) {                         // torch.nn.utils.clip_grad_norm_: coef = max/(norm+1e-6), clamped to 1
         clip = max_norm / (gnorm[0] + 1e-6f);
         clip = clip > 1.0f ? 1.0f : clip;
     }
-    const float lr_bc1 = lr / bc1;
     if (i4 < n4) {
         float4 pw = reinterpret_cast<float4*>(p)[i4], mi = reinterpret_cast<float4*>(m)[i4], vi = reinterpret_cast<float4*>(v)[i4];
         const float4 gq = reinterpret_cast<const float4*>(g)[i4];
-        adam_one(pw.x, gq.x, mi.x, vi.x, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
-        adam_one(pw.y, gq.y, mi.y, vi.y, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
-        adam_one(pw.z, gq.z, mi.z, vi.z, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
-        adam_one(pw.w, gq.w, mi.w, vi.w, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+        adam_one(pw.x, gq.x, mi.x, vi.x, clip, lr_bc1, b1, b2, omb1, omb2, eps, wd, bc2_sqrt);
+        adam_one(pw.y, gq.y, mi.y, vi.y, clip, lr_bc1, b1, b2, omb1, omb2, eps, wd, bc2_sqrt);
+        adam_one(pw.z, gq.z, mi.z, vi.z, clip, lr_bc1, b1, b2, omb1, omb2, eps, wd, bc2_sqrt);
+        adam_one(pw.w, gq.w, mi.w, vi.w, clip, lr_bc1, b1, b2, omb1, omb2, eps, wd, bc2_sqrt);
         reinterpret_cast<float4*>(p)[i4] = pw; reinterpret_cast<float4*>(m)[i4] = mi; reinterpret_cast<float4*>(v)[i4] = vi;
     } else {
         for (int64_t i = n4 << 2; i < n; ++i) {
             float pw = p[i], mi = m[i], vi = v[i];
-            adam_one(pw, g[i], mi, vi, clip, lr_bc1, b1, b2, eps, wd, bc2_sqrt);
+            adam_one(pw, g[i], mi, vi, clip, lr_bc1, b1, b2, omb1, omb2, eps, wd, bc2_sqrt);
             p[i] = pw; m[i] = mi; v[i] = vi;
         }
     }
@@ -1246,13 +1255,13 @@ extern "C" int y5m_grad_norm(const float* g, int64_t n, float* norm_out, void* w
     return Y5M_OK;
 }
 extern "C" int y5m_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm, float max_norm,
-                             float lr, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_step,
+                             double lr, double beta1, double beta2, double eps, double weight_decay, const int32_t* d_step,
                              void* stream) {
     Y5M_REQUIRE(d_step != nullptr, "d_step (device int32, >= 1) is required");
     Y5M_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0,
                 "adam buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((n >> 2) + 1)), dim3(EW_T), 0, y5m_stream(stream), p, g, m, v, n, gnorm, max_norm, lr,
-                       beta1, beta2, eps, weight_decay, d_step);
+                       beta1, beta2, (float)eps, (float)weight_decay, d_step);
     Y5M_CHECK_LAUNCH("adam_kernel");
     return Y5M_OK;
 }

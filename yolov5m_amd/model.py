@@ -238,17 +238,18 @@ class YOLOV5m(nn.Module):
             # Y5M_ENGINE_CACHE caps the COUNT (default 16).
             cap = max(1, int(os.environ.get("Y5M_ENGINE_CACHE", "16")))
             gb = float(os.environ.get("Y5M_ENGINE_CACHE_GB", "0"))
-            budget = gb * 2**30 if gb > 0 else 0.6 * torch.cuda.get_device_properties(x.device).total_memory
+            dev = self.flat_params.device                  # (x may be a meta tensor: NativeTrainStep.input_buffer probes with one)
+            budget = gb * 2**30 if gb > 0 else 0.6 * torch.cuda.get_device_properties(dev).total_memory
             per_px = max((e.nbytes / max(e.key[0] * e.key[1] * e.key[2], 1) for e in self._engines.values()
                           if e.key[3:] == key[3:]), default=0.0)
             need = per_px * B * H * W                     # estimate from a resident plan of the same dtype / mode
             while self._engines and (len(self._engines) >= cap or
                                      sum(e.nbytes for e in self._engines.values()) + need > budget):
                 self._engines.pop(next(iter(self._engines))).release()
-            m0 = torch.cuda.memory_allocated(x.device)
+            m0 = torch.cuda.memory_allocated(dev)
             eng = Engine(self, B, H, W, dtype=dt, training=self.training)
             eng.key = key
-            eng.nbytes = max(torch.cuda.memory_allocated(x.device) - m0, 0)
+            eng.nbytes = max(torch.cuda.memory_allocated(dev) - m0, 0)
             while self._engines and sum(e.nbytes for e in self._engines.values()) + eng.nbytes > budget:
                 self._engines.pop(next(iter(self._engines))).release()
         self._engines[key] = eng               # (re-)insert at the most-recently-used end
