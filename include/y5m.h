@@ -165,6 +165,15 @@ int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const 
 /* One implicit-GEMM convolution launch: out[m][n] = sum_{tap,c} in[pix(m,tap)][c] * w[n][tap*Cin+c].
  * Replaces nn.Conv2d of CBL (model.py:12-28) / HEADS (model.py:162) and, with transposed packed
  * weights and mirrored tap offsets, its autograd data-gradient. */
+/* BatchNorm statistics without partial rows (EPI_RAW_STATS with args->bn_acc != NULL): the conv launch ADDS its per-tile
+ * channel sums (sum, sum of squares) as f64 atomics into the accumulator rows bn_acc[slot][2][Np], slot = tile index
+ * modulo y5m_bn_acc_slots(); stats may then be NULL and there is no y5m_bn_finalize launch: y5m_bn_act_fused derives
+ * scale / shift from the accumulators itself. The caller zeroes the rows before the launch. */
+int y5m_bn_acc_slots(void);
+/* 1 unless the environment says Y5M_BN_FUSE=0 (A/B runs): whether callers should use the accumulator form
+ * (y5m_conv_args.bn_acc + y5m_bn_act_fused, y5m_bn_bwd_fused) instead of partial rows + y5m_bn_finalize / y5m_bn_bwd */
+int y5m_bn_fuse_enabled(void);
+
 typedef struct {
     const void* in;      /* activations (ptr, ldin)                                              */
     const void* w;       /* packed weights [Np][Kp], K-contiguous, zero padded                   */
@@ -205,6 +214,8 @@ typedef struct {
     const float* bn_shift2;
     float* bn_part;
     int32_t bn_ldy, bn_ldy2, bn_split, bn_pad_;
+    /* EPI_RAW_STATS only, optional: accumulator rows instead of partial rows (see y5m_bn_acc_slots) */
+    double* bn_acc;               /* [slots][2][Np] f64, device memory, zeroed by the caller       */
 } y5m_conv_args;
 
 int y5m_conv_tile_n(int N);   /* channel tile (48 or 96) the library uses for N output channels */
@@ -307,8 +318,21 @@ int y5m_bn_fold(const float* gamma, const float* beta, const float* running_mean
 /* out = act(y*scale+shift) (+ res): BN normalise + nn.SiLU (model.py:20) + Bottleneck add (:50) */
 int y5m_bn_act(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
                void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream);
+/* Training-mode BatchNorm2d(eps, momentum) (reference model.py:17) + activation + residual straight from the accumulator
+ * rows a y5m_conv launch with bn_acc filled (see y5m_bn_acc_slots): batch statistics, normalise, act in ONE launch, no
+ * y5m_bn_finalize. acc points at this layer's first channel inside rows of ldacc doubles ([slots][2][ldacc]); count =
+ * samples per channel. Writes scale / shift / mean / invstd [C] (the backward pass reads them) and, with update_running,
+ * the running statistics (unbiased variance, as nn.BatchNorm2d). */
+int y5m_bn_act_fused(const void* y, int ldy, const double* acc, int ldacc, int64_t count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                     int update_running, float* scale, float* shift, float* mean_out, float* invstd_out,
+                     const void* res, int ldres, void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream);
 /* autograd of the above: dgamma, dbeta (param grads) and dy given dz */
 size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C);
+/* ... in two launches instead of three: acc [y5m_bn_acc_slots()][2][C] f64, zeroed by the caller, left dirty */
+int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
+                     int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype, void* stream);
 int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
                float* dbeta, int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes,

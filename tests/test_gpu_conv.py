@@ -294,6 +294,75 @@ def test_conv_wgrad(case, dtype):
     assert _relerr(got, w.grad) < TOL[dtype], (case, dtype, _relerr(got, w.grad))
 
 
+# ---- BatchNorm statistics through accumulator rows (y5m_conv_args.bn_acc + y5m_bn_act_fused, csrc/y5m_bnfuse.h): the conv
+# launch adds its channel sums as f64 atomics, the normalise launch derives scale / shift / mean / invstd and the running
+# statistics itself (reference model.py:17 BatchNorm2d(eps=1e-3, momentum=0.03) in train mode, :20 SiLU); against torch
+# batch statistics of the same conv. One case per kernel family (tiled 3x3 stride 2, halo-patch 3x3, pointwise streaming),
+# pixel counts that are not a multiple of any tile, two channel ranges on one launch (the merged C3 pair), more tiles than
+# workgroups, and the whole sequence twice (running statistics updated twice).
+BNFUSE_CASES = [
+    # B, Cin, H, W, Cout, k, s, p, dtype, split, expected kernel family
+    (3, 48, 18, 18, 96, 3, 2, 1, "f32", None, "tiled"),
+    (3, 48, 18, 18, 96, 3, 2, 1, "bf16", None, "tiled"),
+    (2, 192, 20, 20, 192, 3, 1, 1, "bf16", None, "halo"),
+    (3, 64, 9, 11, 192, 3, 1, 1, "bf16", None, "halo"),
+    (2, 96, 48, 50, 96, 1, 1, 0, "bf16", 48, "pointwise"),
+    (5, 96, 80, 80, 192, 1, 1, 0, "bf16", 96, "pointwise"),
+    (2, 768, 4, 4, 384, 1, 1, 0, "bf16", None, "tiled"),
+    (40, 192, 20, 20, 192, 3, 1, 1, "bf16", None, "halo"),      # more tiles than workgroups: several tiles per block
+]
+
+
+@pytest.mark.parametrize("case", BNFUSE_CASES)
+def test_conv_bn_accumulator_rows(case):
+    from yolov5m_amd import ops
+    from yolov5m_amd.arch import BN_EPS, BN_MOMENTUM
+    B, Cin, H, W, Cout, k, s, p, dtype, split, family = case
+    x = _q(_rand((B, Cin, H, W), 51), dtype)
+    w = _q(_rand((Cout, Cin, k, k), 52, -0.2, 0.2), dtype)
+    gamma, beta = _rand((Cout,), 53, 0.5, 1.5), _rand((Cout,), 54, -0.3, 0.3)
+    rm0, rv0 = _rand((Cout,), 55, -0.5, 0.5), _rand((Cout,), 56, 0.5, 2.0)
+    ref = F.conv2d(x.double(), w.double(), None, s, p)
+    n = ref.numel() // Cout
+    mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + BN_EPS)
+    scale = gamma.double() * invstd
+    shift = beta.double() - mean * scale
+    unb = var * n / (n - 1)
+    rm, rv = rm0.double(), rv0.double()
+    for _ in range(2):
+        rm = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
+        rv = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * unb
+    y, z, g_scale, g_shift, g_mean, g_invstd, g_rm, g_rv = ops.conv_forward_bn_fused(
+        x.to(DEV), w.to(DEV), s, p, gamma.to(DEV), beta.to(DEV), rm0.to(DEV), rv0.to(DEV), BN_MOMENTUM, BN_EPS, dtype,
+        split=split, repeats=2)
+    assert ops.LAST_KERNEL == family, (ops.LAST_KERNEL, family)
+    assert _relerr(y.cpu(), ref.float()) < TOL[dtype]
+    # the sums are taken over the f32 accumulators (before the bf16 store), so the statistics are f32-accurate in both modes
+    tol = dict(rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(g_mean.cpu().numpy(), mean.numpy(), **tol)
+    np.testing.assert_allclose(g_invstd.cpu().numpy(), invstd.numpy(), **tol)
+    np.testing.assert_allclose(g_scale.cpu().numpy(), scale.numpy(), **tol)
+    np.testing.assert_allclose(g_shift.cpu().numpy(), shift.numpy(), **tol)
+    np.testing.assert_allclose(g_rm.cpu().numpy(), rm.numpy(), **tol)
+    np.testing.assert_allclose(g_rv.cpu().numpy(), rv.numpy(), **tol)
+    # the activated output, from the raw output AS STORED (bf16-rounded in bf16 mode) and the reference coefficients
+    zref = F.silu(_q(y.cpu(), dtype).double() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    assert _relerr(z.cpu(), zref.float()) < (1e-2 if dtype == "bf16" else 2e-5)
+
+
+def test_bn_unfused_engine_subprocess():
+    """Y5M_BN_FUSE=0 keeps the engine's three-launch form (partial rows + y5m_bn_finalize / y5m_bn_bwd) alive for A/B runs:
+    the f32 train-step golden runs that way in a child process"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_BN_FUSE") == "0":
+        pytest.skip("already the child")
+    env = dict(os.environ, Y5M_BN_FUSE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(os.path.dirname(__file__), "test_gpu_model.py"), "-q", "-x",
+                        "-k", "train_step_grads_f32_golden and default"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---- training-mode BatchNorm helpers (y5m_bn_finalize / y5m_bn_act / y5m_bn_bwd) against torch fp32 ----
 BN_CASES = [
     # M (pixels), C, ld (row pitch >= C: concat-slice views)
@@ -402,6 +471,17 @@ def test_bn_act_and_backward(case, dtype):
         torch.cuda.synchronize()
         tol = 2e-4 if dtype == "f32" else 2e-2
         assert _relerr(dy.float().cpu(), yc.grad.float()) < tol
+        assert _relerr(dg.cpu(), g64.grad.float()) < 2e-4
+        assert _relerr(db.cpu(), b64.grad.float()) < 2e-4
+    # the two-launch form (y5m_bn_bwd_fused): the reduce adds into f64 accumulator rows, the apply derives its coefficients
+    acc = torch.zeros((L.y5m_bn_acc_slots(), 2, C), dtype=torch.float64, device=DEV)
+    for _ in range(2):
+        dy.zero_(); dg.zero_(); db.zero_(); acc.zero_()
+        _lib.check(L.y5m_bn_bwd_fused(_lib.ptr(dzd), ld, _lib.ptr(yd), ld, _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(mu),
+                                      _lib.ptr(is_), M, C, ACT_SILU, _lib.ptr(dg), _lib.ptr(db), 0, _lib.ptr(dy), C,
+                                      acc.data_ptr(), dt, _lib.stream_ptr()), "bn_bwd_fused")
+        torch.cuda.synchronize()
+        assert _relerr(dy.float().cpu(), yc.grad.float()) < (2e-4 if dtype == "f32" else 2e-2)
         assert _relerr(dg.cpu(), g64.grad.float()) < 2e-4
         assert _relerr(db.cpu(), b64.grad.float()) < 2e-4
 

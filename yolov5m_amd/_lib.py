@@ -36,7 +36,8 @@ class ConvArgs(ctypes.Structure):
                  ("tiles_n", c_int), ("zeros", c_void_p),
                  ("bn_y", c_void_p), ("bn_y2", c_void_p), ("bn_scale", c_void_p), ("bn_shift", c_void_p),
                  ("bn_scale2", c_void_p), ("bn_shift2", c_void_p), ("bn_part", c_void_p),
-                 ("bn_ldy", c_int), ("bn_ldy2", c_int), ("bn_split", c_int), ("bn_pad_", c_int)])
+                 ("bn_ldy", c_int), ("bn_ldy2", c_int), ("bn_split", c_int), ("bn_pad_", c_int),
+                 ("bn_acc", c_void_p)])
 
 
 class WgradArgs(ctypes.Structure):
@@ -127,6 +128,8 @@ _SIGS = {
     "y5m_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y5m_bn_finalize_workspace_bytes": (c_size_t, [c_int]),
+    "y5m_bn_acc_slots": (c_int, []),
+    "y5m_bn_fuse_enabled": (c_int, []),
     "y5m_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                 c_void_p]),
@@ -138,6 +141,11 @@ _SIGS = {
     "y5m_bn_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                            c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int,
                            c_void_p]),
+    "y5m_bn_act_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "y5m_bn_bwd_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "y5m_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                          c_int, c_void_p, c_size_t, c_int, c_void_p]),

@@ -15,6 +15,7 @@
 //   Global->register prefetch of tile k+1 is issued before the MFMAs of tile k (one barrier / tile).
 #pragma once
 #include "y5m_common.h"
+#include "y5m_bnfuse.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

@@ -212,7 +212,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
     const int nb = n0 + wn * NF * 16;
     const int mb = m0 + wm * MF * 16 + frow;
 
-    if (P.epi == EPI_RAW_STATS && P.stats) {
+    if (P.epi == EPI_RAW_STATS && (P.stats || P.bn_acc)) {
         float* red = reinterpret_cast<float*>(smem);          // [2][WM][BN]; tiles are dead after the last barrier
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
@@ -241,7 +241,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + nl];
-            P.stats[((size_t)tile_m * 2 + which) * P.Np + n0 + nl] = t;
+            if (P.bn_acc) bnf_add(P.bn_acc, P.Np, tile_m, which, n0 + nl, t);      // accumulator rows (y5m_bnfuse.h)
+            else P.stats[((size_t)tile_m * 2 + which) * P.Np + n0 + nl] = t;
         }
     }
 
@@ -565,8 +566,9 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     Y5M_REQUIRE(P.M == P.B * P.Hg * P.Wg && P.M > 0, "M");
     Y5M_REQUIRE(P.epi == EPI_HEAD || (P.N % 4 == 0 && P.ldout % 4 == 0), "N/ldout must be multiples of 4");
     const int BN = y5m_conv_tile_n(P.N);
-    Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
+    Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !(P.stats || P.bn_acc) || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
     Y5M_REQUIRE(P.Np >= (P.N + BN - 1) / BN * BN, "Np (rows of the packed weights) must cover the channel tiles");
+    Y5M_REQUIRE(!P.bn_acc || P.epi == EPI_RAW_STATS, "bn_acc: EPI_RAW_STATS launches only");
     if (P.bn_part) {
         const bool dense_out = P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 && P.Hout == P.Hg && P.Wout == P.Wg;
         Y5M_REQUIRE(P.epi == EPI_DGRAD && dense_out, "bn_part: dense stride-1 data-gradient launches only");
@@ -582,7 +584,8 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     Y5M_REQUIRE(img_in < (1ull << 31) && (size_t)P.Hin * P.Win < (1ull << 22), "one input image must be < 2 GiB and < 2^22 pixels");
     const int per_slab = (int)(((1ull << 31) - 1) / img_in);
     if (P.B <= per_slab) return conv_dispatch(P, dtype, st);
-    Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats, "training-mode conv (stats epilogue): input view must be < 2 GiB");
+    // (accumulator rows -- bn_acc -- simply keep adding across the slabs; partial rows are indexed per launch)
+    Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !P.stats, "training-mode conv with partial rows (stats): input view must be < 2 GiB");
     for (int b0 = 0; b0 < P.B; b0 += per_slab) {
         ConvParams S = P;
         S.B = P.B - b0 < per_slab ? P.B - b0 : per_slab;

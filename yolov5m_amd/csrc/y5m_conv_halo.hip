@@ -273,6 +273,9 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
                     for (int r = 0; r < 4; ++r) { sv[r] = hl_row_sum(sv[r]); ss[r] = hl_row_sum(ss[r]); }
                     if (frow == 0) {
                         const int n = nb + hl_pch<NF>(a, fq * 4);
+                        // (with accumulator rows -- P.bn_acc -- the rows are this workgroup's private staging: see the
+                        //  end of the kernel. Atomics issued from here, 8 per lane and fragment with 4 active lanes, cost
+                        //  the forward launches 74 -> 127 us: VMEM issue slots inside the MFMA stream)
                         float* row = P.stats + ((size_t)(etile * 4 + wm) * 2) * P.Np + n;
                         *reinterpret_cast<float4*>(row) = make_float4(sv[0], sv[1], sv[2], sv[3]);
                         *reinterpret_cast<float4*>(row + P.Np) = make_float4(ss[0], ss[1], ss[2], ss[3]);
@@ -478,6 +481,32 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();
     if (pending) epilogue();
+    if constexpr (EPI == EPI_RAW_STATS) {
+        if (P.bn_acc && P.stats) {
+            // accumulator rows (y5m_bnfuse.h): the workgroup sums the 4 partial rows of each of ITS tiles (its own stores:
+            // drained, then read back past the L1) and adds the tiles' totals -- 2 * BN atomics per run of tiles that share
+            // a channel tile, issued once, behind the last MFMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int which = tid / BN, cl = tid - which * BN;
+                float tot = 0.f;
+                int cur_n0 = -1, cur_tile = 0;
+                for (int t = hl_logical_id(blockIdx.x, nblk); t < G.total; t += nblk) {
+                    const int tile_m = t / G.tiles_n, n0 = (t - tile_m * G.tiles_n) * BN;
+                    if (n0 != cur_n0) {
+                        if (cur_n0 >= 0) bnf_add(P.bn_acc, P.Np, cur_tile, which, cur_n0 + cl, tot);
+                        tot = 0.f; cur_n0 = n0; cur_tile = tile_m;
+                    }
+                    const float* row = P.stats + ((size_t)(tile_m * 4) * 2 + which) * P.Np + n0 + cl;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        tot += __hip_atomic_load(row + (size_t)w * 2 * P.Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (cur_n0 >= 0) bnf_add(P.bn_acc, P.Np, cur_tile, which, cur_n0 + cl, tot);
+            }
+        }
+    }
 #ifdef HL_TIMING
     if (blockIdx.x == 0 && (wid == 0 || wid == 4) && lane == 0)
         for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(const_cast<void*>(P.zeros))[32 + (wid ? 8 : 0) + i] = tacc[i];
@@ -500,6 +529,7 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     if (P.osy != 1 || P.osx != 1 || P.ooy != 0 || P.oox != 0) return false;
     if (P.epi != EPI_RAW_STATS && P.epi != EPI_AFFINE_ACT && P.epi != EPI_DGRAD) return false;
     if (P.bn_part) return false;
+    if (P.bn_acc && !P.stats) return false;                 // accumulator rows: this kernel stages its tiles' sums in stats rows
     if (P.Cin < 64 || P.Cin % 32 != 0 || P.ldin % 8 != 0) return false;
     if (P.N % 96 != 0) return false;
     BN = (P.N % 192 == 0 && P.Cin % 64 == 0) ? 192 : 96;

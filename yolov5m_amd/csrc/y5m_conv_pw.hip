@@ -260,7 +260,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
 
     if constexpr (SUMS) {
         float* const rows_out = BNR ? P.bn_part : P.stats;
-        if (rows_out) {
+        const bool fuse = !BNR && P.bn_acc != nullptr;           // accumulator rows instead of partial rows (y5m_bnfuse.h)
+        if (rows_out || fuse) {
             // lanes -> wave (16 pixel lanes share a channel set), waves -> workgroup (through LDS, behind the
             // weights), one stats row per WORKGROUP: row `sblock`; rows sblock + k*gridDim-per-chunk are zero
             // padding so that the consumer (y5m_bn_finalize over stat_rows rows) needs no knowledge of the launch
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
                 const int which = t / NC, c = t - which * NC;
                 const float v = red[(0 * 2 + which) * NC + c] + red[(1 * 2 + which) * NC + c] +
                                 red[(2 * 2 + which) * NC + c] + red[(3 * 2 + which) * NC + c];
+                if (fuse) { bnf_add(P.bn_acc, P.Np, sblock, which, n0 + c, v); continue; }
                 for (int row = sblock, first = 1; row < stat_rows; row += nsb, first = 0)
                     rows_out[((size_t)row * 2 + which) * P.Np + n0 + c] = first ? v : 0.f;
             }
@@ -309,7 +311,7 @@ static int launch_pw(const ConvParams& P, hipStream_t st) {
     if (sblocks < 8) sblocks = 8;
     const int need = (ngroups + 3) / 4;
     if (sblocks > (need + 7) / 8 * 8) sblocks = (need + 7) / 8 * 8;
-    if (((EPI == EPI_RAW_STATS && P.stats) || BNR) && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
+    if (((EPI == EPI_RAW_STATS && P.stats && !P.bn_acc) || BNR) && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
     if (sblocks < 8) return 0;                                       // tiny problem: leave it to the tiled kernel
     const int nstreams = sblocks * 4;
     const size_t lds = (size_t)NCF * KS * 64 * 16 + ((EPI == EPI_RAW_STATS || BNR) ? 4 * 2 * NC * sizeof(float) : 0);
@@ -360,7 +362,7 @@ static int tap_kind(const ConvParams& P, int dtype) {
     if (!dense_out || P.M % 16 != 0 || P.bn_part || P.epi == EPI_HEAD) return 0;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return 0;
     if (P.res && P.ldres % 4 != 0) return 0;
-    if (P.epi == EPI_RAW_STATS && (!P.stats || (P.M + CV_BM - 1) / CV_BM < 8)) return 0;
+    if (P.epi == EPI_RAW_STATS && (!(P.stats || P.bn_acc) || (P.M + CV_BM - 1) / CV_BM < 8)) return 0;
     if ((size_t)P.B * P.Hin * P.Win * P.ldin * 2 >= (1ull << 31)) return 0;          // 32-bit pixel arithmetic in the loader
     if (on && P.Cin == 16 && P.N == 48 && P.Kp >= 160 && P.sy == 1 && P.sx == 1 && !P.res && !P.accumulate &&
         (P.epi == EPI_RAW_STATS || P.epi == EPI_AFFINE_ACT))

@@ -396,7 +396,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     if (g_plan_only) return Y5M_OK;
     static int sb = -1;                                   // single LDS buffer (default; Y5M_WGRAD_SB=0: double buffer): in the full step -0.15 ms
     if (sb < 0) { const char* e = getenv("Y5M_WGRAD_SB"); sb = e ? atoi(e) : 1; }
-    const bool use_sb = sb && TPB == 1;
+    const bool use_sb = sb && TPB == 1 && !(NFR == 6 && CFR == 6 && WK == 2);   // the 8-wave 192 x 192 tile owns its CU: double buffer, one barrier per chunk
     const size_t red_bytes = WK > 1 ? (size_t)(WK - 1) * WN * WC * NFR * CFR * 4 * 64 * sizeof(float) : 0;
     const size_t tile_bytes = (use_sb ? 1 : 2) * (size_t)(C::YB + C::XB);
     const size_t lds = tile_bytes > red_bytes ? tile_bytes : red_bytes;
@@ -437,6 +437,11 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     if (big < 0) { const char* e = getenv("Y5M_WGRAD_BIG"); big = e ? atoi(e) : 1; }
     if (big == 2 && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6>(P, st);
     if (big == 3 && P.N % 192 == 0) return launch_wgrad<T, 4, 2, 1, 3, 1, 3>(P, st);        // 192 x 96, 8 waves of 48 x 48
+    // Y5M_WGRAD_BIG=4: 192 x 192 block, 8 waves = 2 K-waves of 96 x 96 (227 VGPRs, double-buffered LDS, one block per CU).
+    // Measured (round 2, B=64): isolated 585 vs 570 TFLOP/s on 192 -> 192 @ 40x40, 599 vs 517 on 384 -> 384 @ 20x20,
+    // 444 vs 355 on the 384 -> 768 stride-2 layer, 461 vs 497 on 192 -> 384 stride 2 -- but 28.95 vs 28.08 ms/step inside
+    // the train step, where the weight gradient shares the chip with the BatchNorm backward: off.
+    if (big == 4 && P.N % 192 == 0 && P.C % 192 == 0 && taps > 1) return launch_wgrad<T, 2, 2, 2, 6, 1, 6>(P, st);
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
 }

@@ -477,39 +477,80 @@ static inline EwGeom ew_geom(int64_t M, int C8, int max_gx, int threads = 256) {
     return g;
 }
 
+// FUSED forms of the BatchNorm consumers (y5m_bnfuse.h): the per-channel sums come from the accumulator rows the
+// producer launch added into, and every workgroup derives the coefficients of ITS channel group in a prologue (one L2
+// round trip + a little f64 arithmetic, next to the other resident workgroups' streaming); the workgroups with
+// blockIdx.x == 0 also write the per-channel arrays other launches read.
+#define BNF_EW_GX 1536       /* grid cap of the fused consumers (see y5m_bn_act_fused) */
+struct BnFusedFwd {
+    const double* acc; int ldacc;     // [BNF_SLOTS][2][ldacc], already offset to this layer's first channel
+    double count;
+    const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps;
+    float* scale; float* shift; float* mean_o; float* invstd_o; int update_running;
+};
+
 // z = act(y*scale + shift) (+ res)
-template <typename T>
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const T* __restrict__ res, int ldres,
-                                                    T* __restrict__ out, int ldout, int64_t M, int CG, int RP, int act) {
+                                                    T* __restrict__ out, int ldout, int64_t M, int CG, int RP, int act,
+                                                    const BnFusedFwd F) {
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
-    if (rl >= RP) return;
     const int c = (blockIdx.y * CG + cl) * 8;
-    float sc[8], sh[8];
-    load8<float>(scale + c, sc);
-    load8<float>(shift + c, sh);
     const int64_t stride = (int64_t)gridDim.x * RP;
-    auto one = [&](int64_t m) __attribute__((always_inline)) {
-        float v[8];
-        LOAD8_STREAM<T>(y + m * ldy + c, v);
-        float r[8];
-        if (res) load8<T>(res + m * ldres + c, r);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = v[k] * sc[k] + sh[k];
-            if (act == Y5M_ACT_SILU) v[k] = silu_f(v[k]);
-            if (res) v[k] += r[k];
-        }
-        store8<T>(out + m * ldout + c, v);
-    };
     int64_t m = (int64_t)blockIdx.x * RP + rl;
-    for (; m + 3 * stride < M; m += 4 * stride) {
-        float v[4][8], r[4][8];
+    const bool active = rl < RP;
+    float sc[8], sh[8];
+    float v[4][8], r[4][8];
+    // FUSED: the first four rows are requested BEFORE the coefficient prologue, so that its round trip to the accumulator
+    // rows and its f64 arithmetic run under their HBM latency (without this every workgroup starts with ~3 us of nothing in
+    // flight: +4 us per launch with the ~4 rounds of workgroups a CU runs)
+    const bool first4 = FUSED && active && m + 3 * stride < M;
+    if (first4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, v[u]);
             if (res) load8<T>(res + (m + u * stride) * ldres + c, r[u]);
         }
+    }
+    if constexpr (FUSED) {
+        __shared__ float s_co[2][256];                      // CG * 8 <= 256 channels per workgroup
+        const int nch = CG * 8, cbase = blockIdx.y * nch;
+        for (int i = threadIdx.x; i < nch; i += 256) {
+            const int ch = cbase + i;
+            double da, db;
+            bnf_sum(F.acc, F.ldacc, ch, da, db);
+            // same arithmetic as bn_reduce_finalize_kernel<0>
+            const double mean = da / F.count;
+            double var = db / F.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)F.eps));
+            const float s1 = F.gamma[ch] * invstd;
+            const float s0 = F.beta[ch] - (float)mean * s1;
+            s_co[0][i] = s1;
+            s_co[1][i] = s0;
+            if (blockIdx.x == 0) {
+                F.scale[ch] = s1;
+                F.shift[ch] = s0;
+                F.mean_o[ch] = (float)mean;
+                F.invstd_o[ch] = invstd;
+                if (F.update_running) {
+                    const double unb = F.count > 1.0 ? var * F.count / (F.count - 1.0) : var;
+                    F.rmean[ch] = (1.0f - F.momentum) * F.rmean[ch] + F.momentum * (float)mean;
+                    F.rvar[ch] = (1.0f - F.momentum) * F.rvar[ch] + F.momentum * (float)unb;
+                }
+            }
+        }
+        __syncthreads();
+        if (!active) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = s_co[0][cl * 8 + k]; sh[k] = s_co[1][cl * 8 + k]; }
+    } else {
+        if (!active) return;
+        load8<float>(scale + c, sc);
+        load8<float>(shift + c, sh);
+    }
+    auto finish4 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -520,16 +561,71 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
             }
             store8<T>(out + (m + u * stride) * ldout + c, v[u]);
         }
+    };
+    if (first4) { finish4(); m += 4 * stride; }
+    for (; m + 3 * stride < M; m += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, v[u]);
+            if (res) load8<T>(res + (m + u * stride) * ldres + c, r[u]);
+        }
+        finish4();
     }
-    for (; m < M; m += stride) one(m);
+    for (; m < M; m += stride) {
+        float w[8], q[8];
+        LOAD8_STREAM<T>(y + m * ldy + c, w);
+        if (res) load8<T>(res + m * ldres + c, q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            w[k] = w[k] * sc[k] + sh[k];
+            if (act == Y5M_ACT_SILU) w[k] = silu_f(w[k]);
+            if (res) w[k] += q[k];
+        }
+        store8<T>(out + m * ldout + c, w);
+    }
 }
 
 extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
                           void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream) {
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     const EwGeom g = ew_geom(M, C / 8, 4096);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<T>, dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
-                                         (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act);)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
+                                         (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act,
+                                         BnFusedFwd{});)
+    Y5M_CHECK_LAUNCH("bn_act_kernel");
+    return Y5M_OK;
+}
+
+// Y5M_BN_FUSE (default 1): accumulator rows + fused consumers (y5m_bnfuse.h); 0 = partial rows + bn_reduce_finalize_kernel
+// everywhere (A/B runs); 2 = forward only, 3 = backward only
+static int bn_fuse_mode(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("Y5M_BN_FUSE"); v = e ? atoi(e) : 1; }
+    return v;
+}
+extern "C" int y5m_bn_fuse_enabled(void) { return bn_fuse_mode(); }
+extern "C" int y5m_bn_acc_slots(void) { return BNF_SLOTS; }
+
+// training-mode BatchNorm + activation straight from the accumulator rows a y5m_conv(bn_acc) launch filled:
+// finalise (reference model.py:17: eps, momentum, biased batch variance for the normalisation, unbiased for the running
+// estimate) + normalise + act (+ res) in ONE launch. acc points at this layer's first channel inside rows of ldacc
+// doubles. Writes scale / shift / mean / invstd [C] (read by the backward pass) and updates the running statistics.
+extern "C" int y5m_bn_act_fused(const void* y, int ldy, const double* acc, int ldacc, int64_t count, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                int update_running, float* scale, float* shift, float* mean_out, float* invstd_out,
+                                const void* res, int ldres, void* out, int ldout, int64_t M, int C, int act, int dtype,
+                                void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    Y5M_REQUIRE(acc && gamma && beta && scale && shift && mean_out && invstd_out, "null pointer");
+    Y5M_REQUIRE(!update_running || (running_mean && running_var), "running statistics missing");
+    // (every workgroup pays the coefficient prologue, so fewer, longer workgroups than the plain form: 4096 / 2048 / 1536 /
+    //  1024 = 27.44 / 27.24 / 27.14 / 27.3 ms per step, B=64 @ 640^2; the plain form wants 4096)
+    const EwGeom g = ew_geom(M, C / 8, BNF_EW_GX);
+    const BnFusedFwd F{acc, ldacc, (double)count, gamma, beta, running_mean, running_var, momentum, eps,
+                       scale, shift, mean_out, invstd_out, update_running};
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
+                                         (const T*)y, ldy, (const float*)nullptr, (const float*)nullptr, (const T*)res, ldres,
+                                         (T*)out, ldout, M, g.CG, g.RP, act, F);)
     Y5M_CHECK_LAUNCH("bn_act_kernel");
     return Y5M_OK;
 }
@@ -549,11 +645,14 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
 #ifndef BNR_THREADS
 #define BNR_THREADS 256
 #endif
+// accum != NULL: the block partials are ADDED into the accumulator rows accum[BNF_SLOTS][2][C] (y5m_bnfuse.h) instead of
+// being stored as partial rows
 template <typename T>
 __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                            int ldy, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
-                                                           int64_t M, int C, int CG, int RP, int act, float* __restrict__ part) {
+                                                           int64_t M, int C, int CG, int RP, int act, float* __restrict__ part,
+                                                           double* __restrict__ accum) {
     __shared__ float sm[2][BNR_THREADS][9];    // [which][thread][k] (+1: the 8-float rows land on distinct banks)
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
     const bool active = rl < RP;
@@ -605,36 +704,74 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
         const int which = t / NCH, ch = t - which * NCH;
         float acc = 0.f;
         for (int r = 0; r < RP; ++r) acc += sm[which][r * CG + (ch >> 3)][ch & 7];
-        part[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * NCH + ch] = acc;
+        if (accum) bnf_add(accum, C, blockIdx.x, which, blockIdx.y * NCH + ch, acc);
+        else part[((size_t)blockIdx.x * 2 + which) * C + blockIdx.y * NCH + ch] = acc;
     }
 }
 
 // dy = scale*dt + cB*(y - mean) + cD   (mean == NULL: the uncentred coefficients of the fused-reduction path, y as is)
-template <typename T>
+struct BnFusedBwd {
+    const double* acc;                // [BNF_SLOTS][2][C]: (sum dt, sum dt*(y - mean)) from bn_bwd_reduce_kernel
+    const float* invstd; float invM;
+    float* dgamma; float* dbeta; int accumulate;
+};
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ cB, const float* __restrict__ cD,
                                                           const float* __restrict__ mean,
-                                                          T* __restrict__ dy, int lddy, int64_t M, int CG, int RP, int act) {
+                                                          T* __restrict__ dy, int lddy, int64_t M, int C, int CG, int RP, int act,
+                                                          const BnFusedBwd G) {
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
-    if (rl >= RP) return;
     const int c = (blockIdx.y * CG + cl) * 8;
-    float sc[8], sh[8], kb[8], kd[8], mu[8];
-    load8<float>(scale + c, sc); load8<float>(shift + c, sh); load8<float>(cB + c, kb); load8<float>(cD + c, kd);
-    if (mean) load8<float>(mean + c, mu);
-    else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) mu[k] = 0.f;
-    }
     const int64_t stride = (int64_t)gridDim.x * RP;
     int64_t m = (int64_t)blockIdx.x * RP + rl;
-    for (; m + 3 * stride < M; m += 4 * stride) {
-        float g[4][8], yv[4][8];
+    const bool active = rl < RP;
+    float sc[8], sh[8], kb[8], kd[8], mu[8];
+    float g[4][8], yv[4][8];
+    // FUSED: first four rows requested ahead of the coefficient prologue (see bn_act_kernel)
+    const bool first4 = FUSED && active && m + 3 * stride < M;
+    if (first4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             LOAD8_STREAM<T>(dz + (m + u * stride) * lddz + c, g[u]);
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, yv[u]);
         }
+    }
+    if constexpr (FUSED) {
+        // the apply coefficients from the reduce launch's accumulator rows (arithmetic of bn_reduce_finalize_kernel<1>,
+        // centred form); blockIdx.x == 0 also writes the parameter gradients
+        __shared__ float s_co[2][256];
+        const int nch = CG * 8, cbase = blockIdx.y * nch;
+        for (int i = threadIdx.x; i < nch; i += 256) {
+            const int ch = cbase + i;
+            double da, db;
+            bnf_sum(G.acc, C, ch, da, db);
+            const float is = G.invstd[ch], s1 = scale[ch];
+            const float dbeta = (float)da;
+            const float dgamma = is * (float)db;
+            s_co[0][i] = -s1 * dgamma * is * G.invM;
+            s_co[1][i] = -s1 * dbeta * G.invM;
+            if (blockIdx.x == 0 && G.dgamma && G.dbeta) {
+                if (G.accumulate) { G.dbeta[ch] += dbeta; G.dgamma[ch] += dgamma; }
+                else { G.dbeta[ch] = dbeta; G.dgamma[ch] = dgamma; }
+            }
+        }
+        __syncthreads();
+        if (!active) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { kb[k] = s_co[0][cl * 8 + k]; kd[k] = s_co[1][cl * 8 + k]; }
+    } else {
+        if (!active) return;
+        load8<float>(cB + c, kb); load8<float>(cD + c, kd);
+    }
+    load8<float>(scale + c, sc); load8<float>(shift + c, sh);
+    if (mean) load8<float>(mean + c, mu);
+    else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mu[k] = 0.f;
+    }
+    auto finish4 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float o[8];
@@ -645,15 +782,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             }
             store8<T>(dy + (m + u * stride) * lddy + c, o);
         }
+    };
+    if (first4) { finish4(); m += 4 * stride; }
+    for (; m + 3 * stride < M; m += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            LOAD8_STREAM<T>(dz + (m + u * stride) * lddz + c, g[u]);
+            LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, yv[u]);
+        }
+        finish4();
     }
     for (; m < M; m += stride) {
-        float g[8], yv[8], o[8];
-        LOAD8_STREAM<T>(dz + m * lddz + c, g);
-        LOAD8_STREAM<T>(y + m * ldy + c, yv);
+        float g1[8], y1[8], o[8];
+        LOAD8_STREAM<T>(dz + m * lddz + c, g1);
+        LOAD8_STREAM<T>(y + m * ldy + c, y1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
-            o[k] = sc[k] * dt + (kb[k] * (yv[k] - mu[k]) + kd[k]);
+            const float dt = act == Y5M_ACT_SILU ? g1[k] * silu_grad(y1[k] * sc[k] + sh[k]) : g1[k];
+            o[k] = sc[k] * dt + (kb[k] * (y1[k] - mu[k]) + kd[k]);
         }
         store8<T>(dy + m * lddy + c, o);
     }
@@ -685,7 +831,8 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     hipStream_t st = y5m_stream(stream);
     const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);   // (swept 256..2048 in the full step: 512 is best)
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, gr.CG, gr.RP, act, part);)
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, gr.CG, gr.RP, act, part,
+                                         (double*)nullptr);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     BnFinArgs F{};
     BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads, 1};
@@ -693,9 +840,32 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
                        st, part, (int)gr.gx, C, C, stage, ctr, F, G);
     Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
     const EwGeom ga = ew_geom(M, C / 8, 4096);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, mean, (T*)dy, lddy, M, ga.CG,
-                                         ga.RP, act);)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, mean, (T*)dy, lddy, M, C, ga.CG,
+                                         ga.RP, act, BnFusedBwd{});)
+    Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return Y5M_OK;
+}
+
+// The same backward in TWO launches: the reduce pass adds its block partials into acc [y5m_bn_acc_slots()][2][C] f64
+// (zeroed by the caller; left dirty), the apply pass derives its coefficients and dgamma / dbeta from them (y5m_bnfuse.h).
+extern "C" int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
+                                float* dbeta, int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype,
+                                void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    Y5M_REQUIRE(acc && scale && shift && mean && invstd, "null pointer");
+    hipStream_t st = y5m_stream(stream);
+    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, gr.CG, gr.RP, act,
+                                         (float*)nullptr, acc);)
+    Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    const BnFusedBwd G{acc, invstd, 1.0f / (float)M, dgamma, dbeta, accumulate_param_grads};
+    const EwGeom ga = ew_geom(M, C / 8, BNF_EW_GX);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, (const float*)nullptr,
+                                         (const float*)nullptr, mean, (T*)dy, lddy, M, C, ga.CG, ga.RP, act, G);)
     Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return Y5M_OK;
 }
@@ -720,9 +890,9 @@ extern "C" int y5m_bn_bwd_from_partials(const float* part, int rows, int ldpart,
                        st, part, rows, ldpart, C, stage, ctr, F, G);
     Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
     const EwGeom ga = ew_geom(M, C / 8, 4096);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
                                          (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (const float*)nullptr,
-                                         (T*)dy, lddy, M, ga.CG, ga.RP, act);)
+                                         (T*)dy, lddy, M, C, ga.CG, ga.RP, act, BnFusedBwd{});)
     Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return Y5M_OK;
 }

@@ -127,6 +127,14 @@ class Engine:
         self._scratch_elems = 0
         self._stats_floats = 0
         self._bnws_bytes = 0
+        # BatchNorm statistics through f64 accumulator rows (csrc/y5m_bnfuse.h): producers add, consumers derive their
+        # coefficients in a prologue -- no partial rows and no finalise launches (158 per step). Y5M_BN_FUSE: 1 (default)
+        # forward and backward, 2 / 3 forward / backward only, 0 the three-launch form
+        mode = int(self.L.y5m_bn_fuse_enabled()) if training else 0
+        self.fuse_f, self.fuse_b = mode in (1, 2), mode in (1, 3)
+        self._slots = int(self.L.y5m_bn_acc_slots())
+        self._accf = self._accb = 0          # doubles of the forward / backward accumulator rows handed out so far
+        self._acc_users = []                 # (conv descriptor, offset): bn_acc is set once the buffer exists
         self._build()
 
     def release(self):
@@ -211,24 +219,42 @@ class Engine:
             self._consume(x)
             self._consume(res)
             a = self._conv_args(x, lay.wf, lay.y.data_ptr(), Ho, Wo, kk, ss, pp, cout, cout, EPI_RAW_STATS, Kp)
-            tiles_m = L.y5m_conv_stats_rows(ctypes.byref(a), dt)      # partial rows this launch writes (kernel dependent)
-            self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np)
             lay.fwd_args = a
-            self._stat_users.append(a)
-            self._run_conv(self.fwd, a)
+            if self.fuse_f:
+                acc_off = self._accf
+                self._accf += self._slots * 2 * Np
+                self._acc_users.append((a, acc_off))
+                if L.y5m_conv_is_halo(ctypes.byref(a), dt):
+                    # the persistent halo-patch kernel stages its tiles' sums in partial rows and adds them once per workgroup
+                    self._stats_floats = max(self._stats_floats, L.y5m_conv_stats_rows(ctypes.byref(a), dt) * 2 * Np)
+                    self._stat_users.append(a)
+                self._run_conv(self.fwd, a)
 
-            def finalize(lay=lay, P=P, tiles_m=tiles_m, Np=Np, M=M, bn=bn):
-                _lib.check(L.y5m_bn_finalize(_lib.ptr(self.stats), tiles_m, Np, lay.cout, M, _lib.ptr(P["g"]),
-                                             _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
-                                             BN_MOMENTUM, BN_EPS, bn[0].data_ptr(), bn[1].data_ptr(),
-                                             bn[2].data_ptr(), bn[3].data_ptr(), 1, _lib.ptr(self.finws),
-                                             self.finws.numel(), st()), "y5m_bn_finalize")
-            self.fwd.append((finalize, ()))
+                def apply(lay=lay, P=P, bn=bn, dest=dest, res=res, M=M, Np=Np, acc_off=acc_off):
+                    _lib.check(L.y5m_bn_act_fused(_lib.ptr(lay.y), lay.cout, self.accf.data_ptr() + 8 * acc_off, Np, M,
+                                                  _lib.ptr(P["g"]), _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
+                                                  BN_MOMENTUM, BN_EPS, 1, bn[0].data_ptr(), bn[1].data_ptr(),
+                                                  bn[2].data_ptr(), bn[3].data_ptr(),
+                                                  res.ptr if res is not None else None, res.ld if res is not None else 0,
+                                                  dest.ptr, dest.ld, M, lay.cout, ACT_SILU, dt, st()), "y5m_bn_act_fused")
+            else:
+                tiles_m = L.y5m_conv_stats_rows(ctypes.byref(a), dt)      # partial rows this launch writes (kernel dependent)
+                self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np)
+                self._stat_users.append(a)
+                self._run_conv(self.fwd, a)
 
-            def apply(lay=lay, bn=bn, dest=dest, res=res, M=M):
-                _lib.check(L.y5m_bn_act(_lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
-                                        res.ptr if res is not None else None, res.ld if res is not None else 0,
-                                        dest.ptr, dest.ld, M, lay.cout, ACT_SILU, dt, st()), "y5m_bn_act")
+                def finalize(lay=lay, P=P, tiles_m=tiles_m, Np=Np, M=M, bn=bn):
+                    _lib.check(L.y5m_bn_finalize(_lib.ptr(self.stats), tiles_m, Np, lay.cout, M, _lib.ptr(P["g"]),
+                                                 _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
+                                                 BN_MOMENTUM, BN_EPS, bn[0].data_ptr(), bn[1].data_ptr(),
+                                                 bn[2].data_ptr(), bn[3].data_ptr(), 1, _lib.ptr(self.finws),
+                                                 self.finws.numel(), st()), "y5m_bn_finalize")
+                self.fwd.append((finalize, ()))
+
+                def apply(lay=lay, bn=bn, dest=dest, res=res, M=M):
+                    _lib.check(L.y5m_bn_act(_lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
+                                            res.ptr if res is not None else None, res.ld if res is not None else 0,
+                                            dest.ptr, dest.ld, M, lay.cout, ACT_SILU, dt, st()), "y5m_bn_act")
             self.fwd.append((apply, ()))
             self._cbl_backward(lay, P)
         else:
@@ -249,6 +275,8 @@ class Engine:
         M, cout = lay.M, lay.cout
         self._scratch_elems = max(self._scratch_elems, M * cout)
         self._bnws_bytes = max(self._bnws_bytes, L.y5m_bn_bwd_workspace_bytes(M, cout))
+        lay.accb_off = self._accb
+        self._accb += self._slots * 2 * cout
         ntap = lay.kk * lay.kk
         lay.gw_off = self._gw_floats
         lay.ldgw = ntap * lay.x.C
@@ -435,6 +463,12 @@ class Engine:
                                            bn[1].data_ptr(), bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU,
                                            _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr, lddy, _lib.ptr(self.bnws),
                                            self._bnws_bytes, dt, st()), "y5m_bn_bwd_from_partials"), ())
+        if self.fuse_b:
+            accp = self.gw.data_ptr() + 4 * self._accb_base + 8 * lay.accb_off       # zeroed with gw at the start of the pass
+            return (lambda: _lib.check(
+                L.y5m_bn_bwd_fused(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
+                                   bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0,
+                                   scratch_ptr, lddy, accp, dt, st()), "y5m_bn_bwd_fused"), ())
         return (lambda: _lib.check(
             L.y5m_bn_bwd(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                          bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr,
@@ -536,10 +570,16 @@ class Engine:
         halves[0][0].pair_buffers = (wf, y2)             # the launch descriptors hold raw pointers: keep the tensors alive
         self._consume(x)
         a = self._conv_args(x, wf, y2.data_ptr(), x.H, x.W, 1, 1, 0, N2, N2, EPI_RAW_STATS, Kp)
-        tiles_m = L.y5m_conv_stats_rows(ctypes.byref(a), dt)
-        self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np2)
         halves[0][0].fwd_args = a
-        self._stat_users.append(a)
+        acc_off = tiles_m = 0
+        if self.fuse_f:
+            acc_off = self._accf
+            self._accf += self._slots * 2 * Np2
+            self._acc_users.append((a, acc_off))
+        else:
+            tiles_m = L.y5m_conv_stats_rows(ctypes.byref(a), dt)
+            self._stats_floats = max(self._stats_floats, tiles_m * 2 * Np2)
+            self._stat_users.append(a)
         self._run_conv(self.fwd, a)
         for lay, P in halves:
             def finalize(lay=lay, P=P):
@@ -548,16 +588,30 @@ class Engine:
                                              _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]), BN_MOMENTUM, BN_EPS,
                                              bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(), bn[3].data_ptr(), 1,
                                              _lib.ptr(self.finws), self.finws.numel(), st()), "y5m_bn_finalize")
-            self.fwd.append((finalize, ()))
 
             def apply(lay=lay):
                 bn = lay.bn
                 _lib.check(L.y5m_bn_act(y2.data_ptr() + lay.off * esz, N2, bn[0].data_ptr(), bn[1].data_ptr(), None, 0,
                                         lay.z.ptr, lay.z.ld, M, cout, ACT_SILU, dt, st()), "y5m_bn_act")
-            self.fwd.append((apply, ()))
+
+            def apply_fused(lay=lay, P=P):
+                bn = lay.bn        # this half's channels start at column lay.off of the merged launch's accumulator rows
+                _lib.check(L.y5m_bn_act_fused(y2.data_ptr() + lay.off * esz, N2, self.accf.data_ptr() + 8 * (acc_off + lay.off),
+                                              Np2, M, _lib.ptr(P["g"]), _lib.ptr(P["b"]), _lib.ptr(P["rm"]), _lib.ptr(P["rv"]),
+                                              BN_MOMENTUM, BN_EPS, 1, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
+                                              bn[3].data_ptr(), None, 0, lay.z.ptr, lay.z.ld, M, cout, ACT_SILU, dt, st()),
+                           "y5m_bn_act_fused")
+            if self.fuse_f:
+                self.fwd.append((apply_fused, ()))
+            else:
+                self.fwd.append((finalize, ()))
+                self.fwd.append((apply, ()))
         # ---- backward: pushed at c1's place, i.e. executed after the whole C3 body, when both dz are final
         self._scratch_elems = max(self._scratch_elems, M * N2)
         self._bnws_bytes = max(self._bnws_bytes, L.y5m_bn_bwd_workspace_bytes(M, cout))
+        for lay, _P in halves:
+            lay.accb_off = self._accb
+            self._accb += self._slots * 2 * cout
         gw_off = self._gw_floats
         self._gw_floats += N2 * K
         need_dx = x.grad is not None
@@ -792,11 +846,19 @@ class Engine:
         self.finws = torch.zeros((L.y5m_bn_finalize_workspace_bytes(16 * first_out + 96),), dtype=torch.uint8, device=self.dev)
         for a in self._stat_users:
             a.stats = self.stats.data_ptr()
+        if self._acc_users:
+            # forward accumulator rows of every layer, zeroed by ONE fill at the start of the pass
+            self.accf = torch.zeros((self._accf,), dtype=torch.float64, device=self.dev)
+            for a, off in self._acc_users:
+                a.bn_acc = self.accf.data_ptr() + 8 * off
+            self.fwd.insert(0, (lambda: self.accf.zero_(), ()))
         if self.training:
             self.scratch2 = [torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev) for _ in range(self.nslots)]
             self.scratch = self.scratch2[0]
             self.bnws = torch.zeros((self._bnws_bytes,), dtype=torch.uint8, device=self.dev)
-            self.gw = torch.zeros((self._gw_floats,), dtype=torch.float32, device=self.dev)
+            # (the backward accumulator rows of the BatchNorm reductions ride behind the packed weight gradients: one fill)
+            self._accb_base = (self._gw_floats + 1) // 2 * 2
+            self.gw = torch.zeros((self._accb_base + (2 * self._accb if self.fuse_b else 0),), dtype=torch.float32, device=self.dev)
             # expand the backward stack in reverse order; plan-time gradient-written flags
             self.bwd.append((lambda: self.gw.zero_(), ()))
             self.bwd.append((lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, ()))

@@ -119,6 +119,56 @@ def conv_forward_stats(x, w, stride, pad, dtype="f32"):
     return from_nhwc(out), s[0, :Cout], s[1, :Cout]
 
 
+def conv_forward_bn_fused(x, w, stride, pad, gamma, beta, running_mean, running_var, momentum, eps, dtype="f32", split=None,
+                          repeats=1):
+    """training-mode CBL forward WITHOUT partial rows / y5m_bn_finalize: the conv adds its channel sums into f64 accumulator
+    rows (y5m_conv_args.bn_acc), y5m_bn_act_fused derives the batch statistics from them and normalises + SiLU. Returns
+    (raw conv output, activated output, scale, shift, mean, invstd, running_mean, running_var).
+    split: channel index where a second BatchNorm layer starts (the merged C3 pair: one conv, two y5m_bn_act_fused calls on
+    column ranges of the same rows). repeats: the whole sequence that many times (running statistics move each time)."""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    _lib.require_cuda(x, w)
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xn = to_nhwc(x, tdt)
+    wf, Kp, Np = pack_fwd(w, dtype)
+    out = torch.zeros((B, Ho, Wo, Cout), dtype=tdt, device=x.device)
+    z = torch.zeros_like(out)
+    M = B * Ho * Wo
+    a = ConvArgs()
+    a.zeros = _lib.zero_page(x.device).data_ptr()
+    a.inp, a.w, a.out = xn.data_ptr(), wf.data_ptr(), out.data_ptr()
+    a.B, a.Hin, a.Win, a.ldin = B, H, W, Cin
+    a.Hg, a.Wg, a.sy, a.sx = Ho, Wo, stride, stride
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -pad, 1, -pad, 1
+    a.Cin, a.K, a.Kp, a.N, a.M = Cin, k * k * Cin, Kp, Cout, M
+    a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = Ho, Wo, Cout, 1, 1, 0, 0
+    a.Np, a.epi = Np, EPI_RAW_STATS
+    g, b = gamma.float().contiguous(), beta.float().contiguous()
+    rm, rv = running_mean.float().clone().contiguous(), running_var.float().clone().contiguous()
+    res = torch.zeros((4, Cout), dtype=torch.float32, device=x.device)      # scale, shift, mean, invstd
+    acc = torch.zeros((L.y5m_bn_acc_slots(), 2, Np), dtype=torch.float64, device=x.device)
+    # (the halo-patch kernel stages its tiles' sums in partial rows before it adds them)
+    stats = torch.zeros((L.y5m_conv_stats_rows(ctypes.byref(a), dt), 2, Np), dtype=torch.float32, device=x.device)
+    a.bn_acc, a.stats = acc.data_ptr(), stats.data_ptr()
+    bounds = [0, Cout] if split is None else [0, split, Cout]
+    esz = 2 if dtype == "bf16" else 4
+    for _ in range(repeats):
+        acc.zero_()
+        _conv(a, dt)
+        for c0, c1 in zip(bounds[:-1], bounds[1:]):
+            _lib.check(L.y5m_bn_act_fused(out.data_ptr() + c0 * esz, Cout, acc.data_ptr() + 8 * c0, Np, M,
+                                          g.data_ptr() + 4 * c0, b.data_ptr() + 4 * c0, rm.data_ptr() + 4 * c0,
+                                          rv.data_ptr() + 4 * c0, momentum, eps, 1, res[0].data_ptr() + 4 * c0,
+                                          res[1].data_ptr() + 4 * c0, res[2].data_ptr() + 4 * c0, res[3].data_ptr() + 4 * c0,
+                                          None, 0, z.data_ptr() + c0 * esz, Cout, M, c1 - c0, ACT_SILU, dt, _lib.stream_ptr()),
+                       "y5m_bn_act_fused")
+    torch.cuda.synchronize()
+    return from_nhwc(out), from_nhwc(z), res[0], res[1], res[2], res[3], rm, rv
+
+
 def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=None):
     """dy (B,Cout,Ho,Wo), w (Cout,Cin,k,k) -> dx (B,Cin,H,W): autograd of conv2d wrt its input.
     init (B,Cin,H,W): accumulate the gradient onto it (the engine's fan-out accumulation).
