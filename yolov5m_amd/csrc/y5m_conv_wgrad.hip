@@ -21,6 +21,14 @@
 // correct, but 545-560 TFLOP/s isolated against 586 for this kernel on 192 -> 192 @ 40x40 (B = 64), and 28.37 vs 27.93
 // ms/step inside the train step: with three 4-wave blocks per CU it spent 49 % of its wave cycles in s_waitcnt (PMC
 // SQ_WAIT_ANY), i.e. it is bound by the latency of its one-chunk-deep operand prefetch, not by the LDS traffic it saves.
+// Round 2, this kernel alone on a CU (one 4-wave block per CU is what the train step gives it next to the BatchNorm
+// backward): 23 % of the bf16 MFMA peak, a chunk period of ~2470 cycles for 576 cycles of MFMA. Tried, each through an
+// env knob, on 192 -> 192 @ 40x40 (B=64): 8 waves as 2 K-waves of 96 x 96 (Y5M_WGRAD_BIG=4: 585 vs 570 TFLOP/s isolated,
+// 28.95 vs 28.08 ms in the step), 8 waves as 2 K-waves of 96 x 48 (BIG=5: 491), a second register set so that the global
+// loads of chunk k+2 fly under chunk k (472: the loop does not wait on vmcnt) -- the ISA shows what it waits on: the
+// compiler's schedule reads each A fragment ONE group of 3 MFMAs (48 cycles) ahead of its use, and a transposing LDS
+// read takes longer than that, 12 times per chunk, with no second wave on the SIMD to cover it. FP (below) reads the
+// fragments of K-step s+1 under the MFMAs of K-step s instead.
 #include "y5m_conv.h"
 #include <stdlib.h>
 
@@ -42,14 +50,14 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* sub, int lane_of
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 
-template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR, int KX = 1>
 struct WgCfg {
     static constexpr int TN = WN * 16 * NFR;                // channels of dY per block
     static constexpr int TC = WC * 16 * CFR;           // (virtual) channels of X per block = TPB taps x CBLK
     static constexpr int CBLK = TC / TPB;              // real channels per tap in the tile
     static_assert(TC % TPB == 0 && CBLK % 16 == 0, "a 16-channel fragment must not straddle two taps");
     static constexpr bool BF = sizeof(T) == 2;
-    static constexpr int KCH = BF ? 32 * (WK > 2 ? WK : 2) : 32;   // pixels per LDS chunk
+    static constexpr int KCH = (BF ? 32 * (WK > 2 ? WK : 2) : 32) * KX;   // pixels per LDS chunk
     static constexpr int CH = BF ? 8 : 4;              // elements per 16-byte chunk
     static constexpr int LDY = BF ? TN : TN + 16;      // f32 row strides (+16: rows k, k+1 on disjoint banks)
     static constexpr int LDX = BF ? TC : TC + 16;
@@ -73,9 +81,11 @@ __device__ __forceinline__ int lds_chunk_off(int pl, int cc, int tile_ch, int ld
 }
 
 // SB: ONE LDS buffer (two barriers per chunk, half the LDS -> more resident blocks) instead of two
-template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR, bool SB>
+// KX: chunk = KX x 64 pixels (KX x 2 K-steps per wave and chunk). FP: fragment pipelining -- the transposing reads of
+// K-step s+1 are issued one per MFMA of K-step s (sched_group_barrier), into a second fragment register set
+template <typename T, int WN, int WC, int WK, int CFR, int TPB, int NFR, bool SB, int KX = 1, bool FP = false>
 __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradParams P) {
-    using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR>;
+    using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR, KX>;
     constexpr int KCH = C::KCH, CH = C::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -210,7 +220,50 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* Ys = smem + buf * (C::YB + C::XB);
         const unsigned char* Xs = Ys + C::YB;
-        if constexpr (C::BF) {
+        if constexpr (C::BF && FP) {
+            constexpr int KS = KCH / 32 / WK;
+            const int lane_off = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+            uint4 ya[2][NFR], xb[2][CFR];
+            auto rd = [&](int s, uint4* yr, uint4* xr) __attribute__((always_inline)) {
+                const int ks = wk * KS + s;
+                // X fragments first: every one of them is an operand of the K-step's FIRST MFMAs (a outer, b inner), the
+                // dY fragment read last only of its last CFR ones
+#pragma unroll
+                for (int b = 0; b < CFR; ++b) {
+                    const unsigned char* sub = Xs + (ks * (C::TC / 16) + wc * CFR + b) * WG_SUB;
+                    const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
+                    xr[b] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+                }
+#pragma unroll
+                for (int a = 0; a < NFR; ++a) {
+                    const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * NFR + a) * WG_SUB;
+                    const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
+                    yr[a] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+                }
+            };
+            rd(0, ya[0], xb[0]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) rd(s + 1, ya[(s + 1) & 1], xb[(s + 1) & 1]);
+#pragma unroll
+                for (int a = 0; a < NFR; ++a)
+#pragma unroll
+                    for (int b = 0; b < CFR; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ya[s & 1][a]),
+                                                                            __builtin_bit_cast(bf16x8_t, xb[s & 1][b]), acc[a][b], 0, 0, 0);
+            }
+            // the schedule of the whole chunk, in program order: the 2 * (NFR + CFR) reads of K-step 0; then per K-step two of
+            // its MFMAs, two reads (one fragment) of the next K-step, ...; the last K-step's MFMAs back to back
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NFR + CFR), 0);
+#pragma unroll
+            for (int s = 0; s + 1 < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < NFR + CFR; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x008, NFR * CFR, 0);
+        } else if constexpr (C::BF) {
             constexpr int KS = KCH / 32 / WK;           // k-steps (32 pixels) of this wave per chunk
             const int lane_off = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 #pragma unroll
@@ -339,9 +392,9 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
 static thread_local bool g_plan_only = false;   // y5m_wgrad_slices: run the dispatch + split-K sizing, launch nothing
 static thread_local int g_plan_slices = 0;
 
-template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3, int KX = 1, bool FP = false>
 static int launch_wgrad(WgradParams& P, hipStream_t st) {
-    using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR>;
+    using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR, KX>;
     P.tiles_n = (P.N + C::TN - 1) / C::TN;
     P.tiles_c = (P.C + C::CBLK - 1) / C::CBLK;
     const int taps = (P.th * P.tw) / TPB;                 // tap groups (blocks along the tap axis)
@@ -401,15 +454,15 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     const size_t tile_bytes = (use_sb ? 1 : 2) * (size_t)(C::YB + C::XB);
     const size_t lds = tile_bytes > red_bytes ? tile_bytes : red_bytes;
     const unsigned grid = (unsigned)(P.tiles_n * P.tiles_c * taps * P.ksplit);
-    auto kern = use_sb ? wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true> : wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>;
+    auto kern = use_sb ? wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true, KX, FP> : wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false, KX, FP>;
     static bool attr = false;
     if (!attr) {
         const int cap = (int)(2 * (size_t)(C::YB + C::XB) > red_bytes ? 2 * (size_t)(C::YB + C::XB) : red_bytes);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true, KX, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false, KX, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr = true;
     }
-    Y5M_NAME_ONLY(Y5M_OK, "wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WN, WC, WK, CFR, TPB, NFR, (int)use_sb);
+    Y5M_NAME_ONLY(Y5M_OK, "wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WN, WC, WK, CFR, TPB, NFR, (int)use_sb, KX, (int)FP);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
     Y5M_CHECK_LAUNCH("wgrad_kernel");
     return Y5M_OK;
@@ -435,6 +488,10 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     // 1.33x fewer staged bytes per MFMA); Y5M_WGRAD_BIG=2: 192 x 192 (wave 96 x 96, one block per CU), 0: off
     static int big = -1;
     if (big < 0) { const char* e = getenv("Y5M_WGRAD_BIG"); big = e ? atoi(e) : 1; }
+    if constexpr (sizeof(T) == 2) {
+        if (big == 2 && P.N % 192 == 0 && P.C % 192 == 0 && getenv("Y5M_WGRAD_FP") && atoi(getenv("Y5M_WGRAD_FP")) == 1)
+            return launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, true>(P, st);
+    }
     if (big == 2 && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6>(P, st);
     if (big == 3 && P.N % 192 == 0) return launch_wgrad<T, 4, 2, 1, 3, 1, 3>(P, st);        // 192 x 96, 8 waves of 48 x 48
     // Y5M_WGRAD_BIG=4: 192 x 192 block, 8 waves = 2 K-waves of 96 x 96 (227 VGPRs, double-buffered LDS, one block per CU).
@@ -442,6 +499,20 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     // 444 vs 355 on the 384 -> 768 stride-2 layer, 461 vs 497 on 192 -> 384 stride 2 -- but 28.95 vs 28.08 ms/step inside
     // the train step, where the weight gradient shares the chip with the BatchNorm backward: off.
     if (big == 4 && P.N % 192 == 0 && P.C % 192 == 0 && taps > 1) return launch_wgrad<T, 2, 2, 2, 6, 1, 6>(P, st);
+    // Y5M_WGRAD_BIG=4: 192 x 192 block, 8 waves = 2 K-waves of 96 x 96 (227 VGPRs, double-buffered LDS, one block per CU).
+    // Measured (round 2, B=64): isolated 585 vs 570 TFLOP/s on 192 -> 192 @ 40x40, 599 vs 517 on 384 -> 384 @ 20x20,
+    // 444 vs 355 on the 384 -> 768 stride-2 layer, 461 vs 497 on 192 -> 384 stride 2 -- but 28.95 vs 28.08 ms/step inside
+    // the train step, where the weight gradient shares the chip with the BatchNorm backward: off.
+    if (big == 4 && P.N % 192 == 0 && P.C % 192 == 0 && taps > 1) return launch_wgrad<T, 2, 2, 2, 6, 1, 6>(P, st);
+    // experiment: the SAME 192 x 96 block tile with 2 K-waves (8 waves of 96 x 48: two waves per SIMD on one block per CU)
+    if (big == 5 && P.N % 192 == 0 && taps > 1) return launch_wgrad<T, 2, 2, 2, 3, 1, 6>(P, st);
+    if constexpr (sizeof(T) == 2) {
+        static int fp = -1;                 // Y5M_WGRAD_FP: 0 = compiler schedule, 1 = fragment pipelining, 2 = + 128-pixel chunks
+        if (fp < 0) { const char* e = getenv("Y5M_WGRAD_FP"); fp = e ? atoi(e) : 0; }
+        if (big && P.N % 192 == 0 && fp == 1) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, true>(P, st);
+        if (big && P.N % 192 == 0 && fp == 2) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 2, true>(P, st);
+        if (big && P.N % 192 == 0 && fp == 3) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 2, false>(P, st);
+    }
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
 }

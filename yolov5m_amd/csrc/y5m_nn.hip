@@ -856,9 +856,11 @@ extern "C" int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     Y5M_REQUIRE(acc && scale && shift && mean && invstd, "null pointer");
     hipStream_t st = y5m_stream(stream);
-    const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, gr.CG, gr.RP, act,
+    static int rgx = -1;                       // Y5M_BNR_GX: workgroups of the reduce pass (no partial rows to pay for here)
+    if (rgx < 0) { const char* e = getenv("Y5M_BNR_GX"); rgx = e ? atoi(e) : BNR_MAX_GX; }
+    const EwGeom grr = ew_geom(M, C / 8, rgx, BNR_THREADS);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(grr.gx, (unsigned)grr.groups), dim3(BNR_THREADS), 0, st,
+                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, grr.CG, grr.RP, act,
                                          (float*)nullptr, acc);)
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     const BnFusedBwd G{acc, invstd, 1.0f / (float)M, dgamma, dbeta, accumulate_param_grads};

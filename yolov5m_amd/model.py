@@ -246,6 +246,10 @@ class YOLOV5m(nn.Module):
             while self._engines and (len(self._engines) >= cap or
                                      sum(e.nbytes for e in self._engines.values()) + need > budget):
                 self._engines.pop(next(iter(self._engines))).release()
+            # (collect first: a dead plan of ANOTHER model is a reference cycle, and if the cyclic GC frees its tens of GB
+            #  while this plan is being built the allocator delta below comes out as zero)
+            import gc
+            gc.collect()
             m0 = torch.cuda.memory_allocated(dev)
             eng = Engine(self, B, H, W, dtype=dt, training=self.training)
             eng.key = key
