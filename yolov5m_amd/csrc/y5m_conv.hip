@@ -36,7 +36,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
     constexpr int THREADS = WM * WN * 64, RSTEP = THREADS / 8;   // RSTEP: tile rows staged per pass (8 chunks per row)
     constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
-    static_assert(BM == CV_BM && (WM * WN == 4 || WM * WN == 8), "tile config");
+    static_assert(BM % CV_BM == 0 && (WM * WN == 4 || WM * WN == 8), "tile config");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int NA = BM * 8 / THREADS;                          // 16-byte chunks per thread (A)
     constexpr int NB = (BN * 8 + THREADS - 1) / THREADS;          // (B)
@@ -457,10 +457,10 @@ static int launch_conv_multi(ConvMulti& MP, hipStream_t st) {
 
 template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR = false>
 static int launch_conv_db(ConvParams& P, hipStream_t st) {
-    constexpr int BN = WN * NF * 16;
-    P.tiles_m = (P.M + CV_BM - 1) / CV_BM;
+    constexpr int BN = WN * NF * 16, BM = WM * MF * 16;
+    P.tiles_m = (P.M + BM - 1) / BM;
     P.tiles_n = (P.N + BN - 1) / BN;
-    const size_t lds = (DB ? 2 : 1) * (size_t)(CV_BM + BN) * 128;
+    const size_t lds = (DB ? 2 : 1) * (size_t)(BM + BN) * 128;
     auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, DB, BNR>;
     static bool attr = false;
     if (!attr) {
@@ -541,6 +541,16 @@ static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
             // Y5M_CONV_W8=1: the same 128x192 tile with 8 waves (64x48 wave tiles): twice the waves per SIMD to
             // hide barrier / LDS / load waits, 40 % more LDS reads per MFMA (A/B knob)
             if (g_w8 < 0) { const char* e = getenv("Y5M_CONV_W8"); g_w8 = e ? atoi(e) : 1; }
+            // Y5M_CONV_BM256: 256-pixel x 192-channel tile, 8 waves of 64 x 96 (the 8 waves of W8 with the wave tile of the
+            // 4-wave form: 29 % fewer LDS fragment bytes per MFMA, one workgroup per CU). Not for launches that write partial
+            // statistics rows (their callers count one row per 128 pixels). 1 = single LDS buffer, 2 = double buffer.
+            static int bm256 = -1;
+            if (bm256 < 0) { const char* e = getenv("Y5M_CONV_BM256"); bm256 = e ? atoi(e) : 0; }
+            const bool rows128 = (P.epi == EPI_RAW_STATS && P.stats && !P.bn_acc) || P.bn_part;
+            if ((bm256 & 3) && !rows128 && (P.M >= 256 * 256 || (bm256 & 4))) {       // (+4: also tiny problems -- the tests)
+                if ((bm256 & 3) == 2) return launch_conv_db<bf16_t, 4, 2, 4, 6, true>(P, st);
+                return launch_conv_db<bf16_t, 4, 2, 4, 6, false>(P, st);
+            }
             if (g_w8) return launch_conv<bf16_t, 2, 4, 4, 3>(P, st);
             return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
         }
