@@ -1,6 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/job18; mkdir -p $O
-timeout 2400 python -m pytest tests/ -q -m gpu > $O/gputest.txt 2>&1
-tail -8 $O/gputest.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+O=$GRAFT_REPO_ROOT/gpurun_out/job21; mkdir -p $O
+run() { timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-detect --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d.get('final_loss'))" | tee -a $O/ab.txt; }
+for i in 1 2 3; do run base; Y5M_WGRAD_DEFER_HALO=1 run defer_halo; done
