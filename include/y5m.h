@@ -237,6 +237,9 @@ int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype);
 /* 1 when y5m_conv would run this launch on the persistent 3x3 halo-patch kernel (bf16, stride 1, >= 64 input channels,
  * output channels a multiple of 96, image width such that two input patches fit the LDS) */
 int y5m_conv_is_halo(const y5m_conv_args* args, int dtype);
+/* 1 when the kernel this RAW_STATS launch maps to stages its tiles' statistics in partial rows even when accumulator rows
+ * (bn_acc) are given -- the persistent 3x3 halo-patch kernel: pass stats (y5m_conv_stats_rows rows) too */
+int y5m_conv_stages_stats(const y5m_conv_args* args, int dtype);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
  * dwgt[n][tap*C + c] += sum_m dy[m][n] * x[pix(m,tap)][c], f32 atomics into a ZEROED packed buffer. */

@@ -231,6 +231,110 @@ def test_pointwise_fused_epilogue(case, res):
     assert _relerr(got, ref) < TOL["bf16"]
 
 
+# ---- 1x1 layers with >= 384 input channels and N % 192 == 0 run on the persistent two-phase GEMM kernel (y5m_conv_gemm.hip)
+# in bf16 once a launch has enough 256-pixel x 192-channel work items for one workgroup per CU (Y5M_CONV_GEMM8_MIN, default
+# 192): the last case below does by itself (876 items: several tiles per workgroup, two channel tiles); the small ones --
+# pixel counts that are not a multiple of the tile, an odd number of 64-channel units, one / two / four channel tiles --
+# reach it in the child process of test_gemm8_small_shapes_subprocess, which lowers the threshold to 1.
+GEMM8_CASES = [
+    # B, Cin, H, W, Cout
+    (3, 384, 9, 11, 192),
+    (2, 448, 20, 20, 384),
+    (1, 768, 16, 16, 768),
+    (70, 384, 40, 40, 384),
+]
+
+
+def _gemm8_expected(case, dgrad=False):
+    """the library's dispatch rule (y5m_conv_gemm.hip gemm8_geom): Y5M_CONV_GEMM8 = 2 (default) takes the forward
+    epilogues only, 1 also the data gradients (the child process of test_gemm8_small_shapes_subprocess)"""
+    import os
+    B, Cin, H, W, Cout = case
+    mode = int(os.environ.get("Y5M_CONV_GEMM8", "2"))
+    if mode == 0 or (mode == 2 and dgrad) or (mode == 3 and not dgrad):
+        return None
+    items = (B * H * W + 255) // 256 * (Cout // 192)
+    return "gemm8" if items >= int(os.environ.get("Y5M_CONV_GEMM8_MIN", "192")) else None
+
+
+def test_gemm8_small_shapes_subprocess():
+    import os, subprocess, sys
+    if os.environ.get("Y5M_CONV_GEMM8_MIN") == "1":
+        pytest.skip("already the child")
+    env = dict(os.environ, Y5M_CONV_GEMM8_MIN="1", Y5M_CONV_GEMM8="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "gemm8 and not subprocess"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", GEMM8_CASES)
+def test_gemm8_forward_epilogues(case):
+    """plain store, folded BN + SiLU + residual, and raw + statistics (partial rows) against torch fp32"""
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout = case
+    x = _q(_rand((B, Cin, H, W), 61), "bf16")
+    w = _q(_rand((Cout, Cin, 1, 1), 62, -0.1, 0.1), "bf16")
+    ref = F.conv2d(x, w)
+    exp = _gemm8_expected(case)
+    got = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 0, "bf16").cpu()          # (plain store = the data-gradient epilogue)
+    assert _gemm8_expected(case, dgrad=True) is None or ops.LAST_KERNEL == "gemm8", ops.LAST_KERNEL
+    assert _relerr(got, ref) < TOL["bf16"]
+    sc, sh = _rand((Cout,), 63, 0.5, 1.5), _rand((Cout,), 64, -0.2, 0.2)
+    r = _q(_rand((B, Cout, H, W), 65), "bf16")
+    ref2 = F.silu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + r
+    got2 = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 0, "bf16", scale=sc.to(DEV), shift=sh.to(DEV), act=True, res=r.to(DEV)).cpu()
+    assert exp is None or ops.LAST_KERNEL == exp, ops.LAST_KERNEL
+    assert _relerr(got2, ref2) < TOL["bf16"]
+    got3, s1, s2 = ops.conv_forward_stats(x.to(DEV), w.to(DEV), 1, 0, "bf16")
+    assert exp is None or ops.LAST_KERNEL == exp, ops.LAST_KERNEL
+    assert _relerr(got3.cpu(), ref) < TOL["bf16"]
+    np.testing.assert_allclose(s1.cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=5e-2)
+    np.testing.assert_allclose(s2.cpu().numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=2e-3, atol=5e-2)
+
+
+@pytest.mark.parametrize("case", GEMM8_CASES)
+def test_gemm8_bn_accumulator_rows(case):
+    from yolov5m_amd import ops
+    from yolov5m_amd.arch import BN_EPS, BN_MOMENTUM
+    B, Cin, H, W, Cout = case
+    x = _q(_rand((B, Cin, H, W), 66), "bf16")
+    w = _q(_rand((Cout, Cin, 1, 1), 67, -0.1, 0.1), "bf16")
+    gamma, beta = _rand((Cout,), 68, 0.5, 1.5), _rand((Cout,), 69, -0.3, 0.3)
+    ref = F.conv2d(x.double(), w.double())
+    mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + BN_EPS)
+    y, z, g_scale, g_shift, g_mean, g_invstd, _rm, _rv = ops.conv_forward_bn_fused(
+        x.to(DEV), w.to(DEV), 1, 0, gamma.to(DEV), beta.to(DEV), torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV),
+        BN_MOMENTUM, BN_EPS, "bf16", repeats=2)
+    exp = _gemm8_expected(case)
+    assert exp is None or ops.LAST_KERNEL == exp, ops.LAST_KERNEL
+    assert _relerr(y.cpu(), ref.float()) < TOL["bf16"]
+    np.testing.assert_allclose(g_mean.cpu().numpy(), mean.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(g_invstd.cpu().numpy(), invstd.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(g_scale.cpu().numpy(), (gamma.double() * invstd).numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("mode", ["plain", "init", "src"])
+@pytest.mark.parametrize("case", GEMM8_CASES)
+def test_gemm8_dgrad(case, mode):
+    """data gradient of a 1x1 conv Cout -> Cin seen from the kernel: K = Cout (>= 384), N = Cin; store, accumulate in place,
+    and the fused residual source"""
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout = case                 # roles swapped: the FORWARD conv maps Cout_k <- Cin_k with Cin_k = Cout here
+    fw_cin, fw_cout = Cout, Cin               # forward conv: fw_cin -> fw_cout; its dgrad has K = fw_cout, N = fw_cin
+    x = _rand((B, fw_cin, H, W), 71).requires_grad_(True)
+    w = _q(_rand((fw_cout, fw_cin, 1, 1), 72, -0.1, 0.1), "bf16")
+    dy = _q(_rand((B, fw_cout, H, W), 73), "bf16")
+    F.conv2d(x, w).backward(dy)
+    ref = x.grad
+    extra = _q(_rand((B, fw_cin, H, W), 74), "bf16")
+    kw = {"init": extra.to(DEV)} if mode == "init" else {"src": extra.to(DEV)} if mode == "src" else {}
+    got = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, 0, "bf16", **kw).cpu()
+    if fw_cout >= 384 and fw_cin % 192 == 0 and _gemm8_expected((B, fw_cout, H, W, fw_cin), dgrad=True):
+        assert ops.LAST_KERNEL == "gemm8", ops.LAST_KERNEL
+    assert _relerr(got, ref + (extra if mode != "plain" else 0)) < TOL["bf16"]
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], (2, 96, 48, 50, 96, 1, 1, 0)])
 def test_conv_dgrad_fused_residual_source(case, dtype):

@@ -521,11 +521,17 @@ extern "C" int y5m_conv_tile_n(int N) {
 
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st);      // y5m_conv_pw.hip
 int y5m_conv_halo_try(const ConvParams& P, int dtype, hipStream_t st);    // y5m_conv_halo.hip
+int y5m_conv_gemm8_try(const ConvParams& P, int dtype, hipStream_t st);   // y5m_conv_gemm.hip
 
 static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
     {
         // 3x3 stride-1 layers with >= 64 input channels: persistent halo-patch kernel (y5m_conv_halo.hip)
         const int r = y5m_conv_halo_try(P, dtype, st);
+        if (r != 0) return r < 0 ? r : Y5M_OK;
+    }
+    {
+        // 1x1 layers with >= 384 input channels and N % 192 == 0: persistent two-phase GEMM kernel (y5m_conv_gemm.hip)
+        const int r = y5m_conv_gemm8_try(P, dtype, st);
         if (r != 0) return r < 0 ? r : Y5M_OK;
     }
     {

@@ -514,6 +514,7 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+int y5m_conv_gemm8_stat_rows(const ConvParams& P, int dtype);      // y5m_conv_gemm.hip
 static int g_halo = -1;            // Y5M_CONV_HALO: 0 = tiled kernel everywhere (A/B runs), 1 (default) = 192-channel tiles only, 2 = also the
                                    // 96-channel tile (N = 96: 24 MFMAs per wave and phase do not cover the other group's R
                                    // phase -- 490-580 TFLOP/s against 520-670 for the tiled kernel on 96 -> 96 @ 80x80)
@@ -566,7 +567,19 @@ extern "C" int y5m_conv_stats_rows(const y5m_conv_args* args, int dtype) {
     HaloArgs G;
     int BN;
     if (halo_geom(P, dtype, G, BN)) return G.stat_rows;
+    const int gr = y5m_conv_gemm8_stat_rows(P, dtype);
+    if (gr > 0) return gr;
     return (P.M + CV_BM - 1) / CV_BM;
+}
+
+// 1 when the kernel y5m_conv would run for this RAW_STATS launch stages its tiles' statistics in partial rows even with
+// accumulator rows (bn_acc): the persistent halo-patch kernel, whose LDS is full -- the caller then passes stats as well
+extern "C" int y5m_conv_stages_stats(const y5m_conv_args* args, int dtype) {
+    ConvParams P;
+    memcpy(&P, args, sizeof(P));
+    HaloArgs G;
+    int BN;
+    return halo_geom(P, dtype, G, BN) ? 1 : 0;         // (the long-K GEMM kernel sums its tiles in an LDS table instead)
 }
 
 // 1 when y5m_conv runs this launch on the halo-patch kernel

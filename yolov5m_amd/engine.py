@@ -224,7 +224,7 @@ class Engine:
                 acc_off = self._accf
                 self._accf += self._slots * 2 * Np
                 self._acc_users.append((a, acc_off))
-                if L.y5m_conv_is_halo(ctypes.byref(a), dt):
+                if L.y5m_conv_stages_stats(ctypes.byref(a), dt):
                     # the persistent halo-patch kernel stages its tiles' sums in partial rows and adds them once per workgroup
                     self._stats_floats = max(self._stats_floats, L.y5m_conv_stats_rows(ctypes.byref(a), dt) * 2 * Np)
                     self._stat_users.append(a)

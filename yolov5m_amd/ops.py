@@ -24,7 +24,10 @@ def _rup(x, m):
 def _conv(a, dt, what="y5m_conv"):
     global LAST_KERNEL
     L = _lib.lib()
+    name = ctypes.create_string_buffer(192)
+    L.y5m_conv_kernel_name(ctypes.byref(a), dt, name, 192)
     LAST_KERNEL = ("halo" if L.y5m_conv_is_halo(ctypes.byref(a), dt) else
+                   "gemm8" if name.value.startswith(b"conv_gemm8") else
                    "pointwise" if L.y5m_conv_is_pointwise(ctypes.byref(a), dt) else "tiled")
     _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), what)
 
