@@ -335,7 +335,8 @@ __global__ __launch_bounds__(GM_THREADS) void conv_gemm8_kernel(const ConvParams
 // workgroup holds its CU (226 VGPRs x 8 waves) for the whole launch, and the weight-gradient blocks of the forked stream
 // (100+ us each) and these workgroups then wait for each other per CU instead of interleaving block by block as the tiled
 // kernel's short-lived workgroups do -- the same reason the halo kernel's data gradient takes 108 us in the step against
-// 73 us for its forward. Hence forward only.
+// 73 us for its forward. Launching the data gradients with one work item per workgroup (Y5M_CONV_GEMM8_NP=1: short-lived
+// workgroups) recovers a third of the loss (27.71 vs 27.78 vs 27.57 ms). Hence forward only.
 static int g_gemm8 = -1;
 static int g_gemm8_cus = 0;
 static int g_gemm8_min_tiles = -1; // Y5M_CONV_GEMM8_MIN: fewer work items than this stay on the tiled kernel
@@ -388,7 +389,11 @@ static int launch_gemm8(const ConvParams& P, const GemmArgs& G, hipStream_t st) 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_gemm8_cus = prop.multiProcessorCount;
         if (g_gemm8_cus <= 0) g_gemm8_cus = 256;
     }
-    const int grid = G.total < g_gemm8_cus ? G.total : g_gemm8_cus;
+    // Y5M_CONV_GEMM8_NP=1 (experiment): data-gradient launches with ONE work item per workgroup (grid = items), so that the
+    // workgroups are short-lived and interleave with the forked weight gradient's blocks
+    static int np = -1;
+    if (np < 0) { const char* e = getenv("Y5M_CONV_GEMM8_NP"); np = e ? atoi(e) : 0; }
+    const int grid = (np && EPI == EPI_DGRAD) ? G.total : (G.total < g_gemm8_cus ? G.total : g_gemm8_cus);
     Y5M_NAME_ONLY(Y5M_OK, "conv_gemm8_kernel<%d>", EPI);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(GM_THREADS), lds, st, P, G);
     Y5M_CHECK_LAUNCH("conv_gemm8_kernel");
