@@ -410,6 +410,63 @@ def test_multi_scale_plan_cache_is_bounded_by_memory(monkeypatch):
         prev = eng
 
 
+def test_multi_scale_all_sizes_twice_subprocess():
+    """runs test_multi_scale_all_sizes_twice_no_allocation_growth in a FRESH process -- the way a training run meets it.
+    In-process, behind tests that have created and destroyed a few dozen captured graphs, the replay of one of its 11
+    resident graphs faulted the GPU on some boxes ("Memory access fault ... Reason: Unknown", gone with
+    AMD_SERIALIZE_KERNEL=3, never in eager mode, never with PYTORCH_NO_CUDA_MEMORY_CACHING=1 in eager mode, never in a fresh
+    process): recorded as an open issue in DESIGN.md section 8; a fault aborts the whole pytest process, so the scenario
+    is kept out of it."""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_MULTISCALE_CHILD") == "1":
+        pytest.skip("already the child")
+    env = dict(os.environ, Y5M_MULTISCALE_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "all_sizes_twice_no_allocation_growth"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_multi_scale_all_sizes_twice_no_allocation_growth(monkeypatch):
+    """the reference's multi_scale (utils/training_utils.py:11-28) draws one of the 11 sizes 320..640 step 32: cycling
+    through ALL of them twice, the second pass finds every plan (and its captured graphs) resident -- same Engine objects,
+    no growth of the allocator's live bytes -- and the graph-replayed run returns the losses of the eager run of the same
+    schedule (each graph replays on ITS plan's loss workspace and step() hands back ITS loss tensor)"""
+    import os
+    if os.environ.get("Y5M_MULTISCALE_CHILD") != "1":
+        pytest.skip("runs in the child process of test_multi_scale_all_sizes_twice_subprocess")
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    monkeypatch.delenv("Y5M_ENGINE_CACHE", raising=False)
+    monkeypatch.delenv("Y5M_ENGINE_CACHE_GB", raising=False)
+    sizes = list(range(320, 641, 32))
+    assert len(sizes) == 11
+    batches = [(synth_images(2, s, s, seed=f"ma{s}").to(DEV), synth_labels(2, 4, seed=f"mal{s}")) for s in sizes]
+    losses = {}
+    for use_graph in (False, True):
+        m = _model("f32"); m.train()
+        step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=use_graph)
+        first, ls = {}, []
+        for s, (x, t) in zip(sizes, batches):
+            ls.append(float(step.step(x, t)[0]))
+            first[s] = next(reversed(m._engines.values()))
+        assert len(m._engines) == 11
+        torch.cuda.synchronize()
+        live = torch.cuda.memory_allocated()
+        for s, (x, t) in zip(sizes, batches):
+            ls.append(float(step.step(x, t)[0]))       # graph mode: REPLAYS the graph captured on the first visit
+            eng = next(reversed(m._engines.values()))
+            assert eng is first[s] and not eng.released
+        torch.cuda.synchronize()
+        assert len(m._engines) == 11
+        assert torch.cuda.memory_allocated() <= live + (1 << 20), (torch.cuda.memory_allocated(), live)
+        losses[use_graph] = ls
+    # the replayed graphs compute THEIR plan's loss on THEIR plan's buffers: step for step the eager run's values (f32;
+    # 22 Adam steps on 2-image batches amplify the reordering of the atomic gradient sums a little)
+    assert np.all(np.isfinite(losses[True]))
+    np.testing.assert_allclose(losses[True][:11], losses[False][:11], rtol=5e-3)
+    np.testing.assert_allclose(losses[True][11:], losses[False][11:], rtol=6e-2)
+
+
 def test_config4_inference_1280_slab_path_and_detect():
     """BASELINE.json configs[4], the detect.py flow (reference detect.py:50-54: model(img) -> cells_to_bboxes -> NMS) at
     batch 128 @ 1280x1280, bf16 eval. The second conv's input view is 5 GB, so y5m_conv runs it (and every other layer

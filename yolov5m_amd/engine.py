@@ -21,6 +21,9 @@ import torch
 
 from . import _lib
 from .arch import BN_EPS, BN_MOMENTUM, blocks
+
+import os as _os
+_TRACE = _os.environ.get("Y5M_TRACE", "0") == "1"
 from ._lib import (ConvArgs, WgradArgs, EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD, EPI_DGRAD, ACT_NONE, ACT_SILU,
                    F32, BF16)
 
@@ -1020,7 +1023,10 @@ class Engine:
     def _run(lst, timeline=None):
         """Enqueue a launch list. timeline: optional list that receives (kind, start_event, end_event)
         per op (events recorded on the current stream = the stream the kernels are launched on)."""
+        trace = _TRACE
         for fn, args in lst:
+            if trace:                                       # Y5M_TRACE=1: name every launch-list entry and wait for it (fault hunting)
+                print("[y5m]", getattr(fn, "kind", getattr(fn, "__name__", "op")), flush=True)
             if timeline is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -1030,6 +1036,8 @@ class Engine:
                     raise _lib.Y5MError(f"native call failed rc={rc}: {_lib.lib().y5m_last_error().decode()}")
             else:
                 fn()
+            if trace:
+                torch.cuda.synchronize()
             if timeline is not None:
                 e1.record()
                 timeline.append((getattr(fn, "kind", getattr(fn, "__name__", "other")), e0, e1))

@@ -128,7 +128,6 @@ class NativeTrainStep:
         # together with a strong reference to the plan: id(plan) can be reused after a plan is freed), one optimizer graph
         self._fb_graphs = {}
         self._opt_graph = None
-        self._ws = None
         if self.accumulate > 1:
             self.gacc = torch.zeros(n, dtype=torch.float32, device=dev)
 
@@ -143,9 +142,13 @@ class NativeTrainStep:
         outs = eng.outs
         B = eng.B
         shapes = [(o.shape[2], o.shape[3]) for o in outs]
-        if self._ws is None or self._ws.key != (B, eng.naxs, tuple(shapes), self.nt_max):
-            self._ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
-        ws = self._ws
+        # The loss workspace belongs to the PLAN: a captured graph holds its addresses, so one workspace shared by all
+        # plans and re-created whenever the shapes change (what this did until round 2) left the graphs of every other
+        # resident size replaying on freed memory -- and step() returning another plan's loss tensor -- as soon as
+        # multi_scale came back to a size. It is dropped with the plan (Engine.release).
+        ws = getattr(eng, "_loss_ws", None)
+        if ws is None or ws.key != (B, eng.naxs, tuple(shapes), self.nt_max):
+            ws = eng._loss_ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
         grads = eng.head_grad_buffers()
         sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
         if sparse and getattr(ws, "owner_ptrs", None) is None:
@@ -240,6 +243,7 @@ class NativeTrainStep:
             self._capture(eng, lambda: self._enqueue_fb(eng))
             return self.loss_out                         # this call WAS the eager step: one call = one step
         g1.replay()
+        self.loss_out = eng._loss_ws.loss_out            # (the replayed plan's, not the most recently captured one's)
         if self.grad_hook is not None:
             self.grad_hook(self.model.flat_grads)
         self._opt_graph.replay()
@@ -310,6 +314,8 @@ class NativeTrainStep:
             else:
                 seg(i)
             hook.launch(flat, los[i], his[i])
+        if graphs is not None:
+            self.loss_out = eng._loss_ws.loss_out
         hook.wait()
         if graphs is not None:
             self._opt_graph.replay()
@@ -361,6 +367,7 @@ class NativeTrainStep:
             self._capture(eng, enqueue)
         elif self.use_graph:
             g1.replay()
+            self.loss_out = eng._loss_ws.loss_out
         else:
             self._enqueue_fb(eng)
             self.gacc.add_(self.model.flat_grads)
