@@ -351,6 +351,20 @@ def test_config2_first_step_loss_golden(golden, dtype, rtol):
     m._engines.clear()
 
 
+@pytest.mark.parametrize("env", [{"Y5M_BN_FUSE": "0"}, {"Y5M_CONV_GEMM8": "0"}, {"Y5M_CONV_GEMM8": "1"}, {"Y5M_CONV_HALO": "0"}])
+def test_config2_first_step_loss_kernel_variants_subprocess(env):
+    """BASELINE.json configs[2] at FULL size (B = 64 @ 640x640, bf16) with each alternative kernel path switched in: the
+    three-launch BatchNorm form, the tiled kernel instead of the long-K GEMM kernel (and that kernel also for the data
+    gradients), the tiled kernel instead of the halo-patch kernel -- the first-step loss must stay on the reference's
+    value whichever kernels compute it (the switches are read once per process: child processes)"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_VARIANT_CHILD") == "1":
+        pytest.skip("already the child")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "config2_first_step_loss_golden and bf16"],
+                       env=dict(os.environ, Y5M_VARIANT_CHILD="1", **env), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (env, r.stdout[-3000:] + r.stderr[-2000:])
+
+
 def test_multi_scale_plan_cache_eviction_and_graphs(monkeypatch):
     """multi_scale training alternates input sizes (reference utils/training_utils.py:11-28): with a plan cache of ONE
     entry every size change evicts the other size's plan (Engine.release: launch lists and tensors dropped, HBM back
