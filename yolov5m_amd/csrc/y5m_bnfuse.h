@@ -18,7 +18,11 @@
 #pragma once
 #include "y5m_common.h"
 
+#ifdef BNF_SLOTS_OVERRIDE            /* experiment builds (tools/bn_bench.py) */
+#define BNF_SLOTS BNF_SLOTS_OVERRIDE
+#else
 #define BNF_SLOTS 8
+#endif
 
 // add one partial sum; which = 0 (first sum) / 1 (second sum), c = channel index inside the row
 __device__ __forceinline__ void bnf_add(double* acc, int ld, int slot, int which, int c, float v) {
