@@ -398,6 +398,56 @@ def test_conv_wgrad(case, dtype):
     assert _relerr(got, w.grad) < TOL[dtype], (case, dtype, _relerr(got, w.grad))
 
 
+# ---- wide-layer weight gradients (the 192 x 96 and 96 x 96 block tiles of wgrad_kernel, and their producer / consumer
+# form wgrad_pc_kernel: Y5M_WGRAD_PC, bit 0 = 192 x 96 tile, bit 1 = 96 x 96 tile, bit 3 = 192 x 192 tile). Ragged pixel counts (tail chunk),
+# widths that are not a multiple of the 64-pixel chunk (rows and images change inside a chunk), stride 2, channel counts
+# that leave a partial channel tile, and enough pixels for several chunks per split-K range.
+WGRAD_WIDE_CASES = [
+    # B, Cin, H, W, Cout, k, s, p
+    (2, 96, 12, 12, 96, 3, 1, 1),
+    (3, 192, 20, 20, 192, 3, 1, 1),
+    (1, 384, 7, 9, 192, 3, 2, 1),
+    (5, 96, 40, 40, 96, 3, 1, 1),
+    (2, 144, 10, 14, 384, 3, 1, 1),
+    (16, 192, 40, 40, 192, 3, 1, 1),
+]
+
+
+def _wgrad_pc_bits():
+    import os
+    return int(os.environ.get("Y5M_WGRAD_PC", "0"))
+
+
+@pytest.mark.parametrize("case", WGRAD_WIDE_CASES)
+def test_conv_wgrad_wide_layers(case):
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    x = _q(_rand((B, Cin, H, W), 21), "bf16")
+    w = _rand((Cout, Cin, k, k), 22, -0.2, 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = _q(_rand(tuple(y.shape), 23), "bf16")
+    y.backward(dy)
+    got = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, "bf16").cpu()
+    bits = _wgrad_pc_bits()
+    wide = Cout % 192 == 0
+    if (bits & 1 and wide) or (bits & 2 and not wide) or (bits & 8 and wide and Cin % 192 == 0):
+        assert ops.LAST_WGRAD_KERNEL.startswith("wgrad_pc_kernel"), ops.LAST_WGRAD_KERNEL
+    assert _relerr(got, w.grad) < TOL["bf16"], (case, ops.LAST_WGRAD_KERNEL, _relerr(got, w.grad))
+
+
+def test_wgrad_other_form_subprocess():
+    """the weight-gradient form that is NOT the default of this build (producer / consumer workgroups vs the 4-wave
+    kernel) on the same cases, in a child process (the knob is read once per process)"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_WGRAD_TEST_CHILD") == "1":
+        pytest.skip("already the child")
+    other = "0" if _wgrad_pc_bits() else "11"
+    env = dict(os.environ, Y5M_WGRAD_PC=other, Y5M_WGRAD_TEST_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "wgrad_wide or test_conv_wgrad"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---- BatchNorm statistics through accumulator rows (y5m_conv_args.bn_acc + y5m_bn_act_fused, csrc/y5m_bnfuse.h): the conv
 # launch adds its channel sums as f64 atomics, the normalise launch derives scale / shift / mean / invstd and the running
 # statistics itself (reference model.py:17 BatchNorm2d(eps=1e-3, momentum=0.03) in train mode, :20 SiLU); against torch

@@ -33,6 +33,9 @@
 #include <stdlib.h>
 
 #define WG_THREADS 256
+#ifndef Y5M_EXP
+#define Y5M_EXP 0     // timing-only ablation builds (tools/exp_wgrad.sh): results are WRONG by construction
+#endif
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -273,21 +276,36 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
 #pragma unroll
                 for (int a = 0; a < NFR; ++a) {
                     const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * NFR + a) * WG_SUB;
+#if Y5M_EXP & 1
+                    ya[a] = *reinterpret_cast<const uint4*>(sub + lane * 16);      // timing ablation: WRONG data
+#else
                     const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
                     ya[a] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+#endif
                 }
 #pragma unroll
                 for (int b = 0; b < CFR; ++b) {
                     const unsigned char* sub = Xs + (ks * (C::TC / 16) + wc * CFR + b) * WG_SUB;
+#if Y5M_EXP & 1
+                    xb[b] = *reinterpret_cast<const uint4*>(sub + lane * 16);
+#else
                     const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
                     xb[b] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+#endif
                 }
+#if !(Y5M_EXP & 8)
 #pragma unroll
                 for (int a = 0; a < NFR; ++a)
 #pragma unroll
                     for (int b = 0; b < CFR; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ya[a]),
                                                                             __builtin_bit_cast(bf16x8_t, xb[b]), acc[a][b], 0, 0, 0);
+#else
+#pragma unroll
+                for (int a = 0; a < NFR; ++a)
+#pragma unroll
+                    for (int b = 0; b < CFR; ++b) acc[a][b][0] += __builtin_bit_cast(float, ya[a].x ^ xb[b].y);
+#endif
             }
         } else {
             const float* Yf = reinterpret_cast<const float*>(Ys);
@@ -319,14 +337,14 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
         int cur = 0;
         for (int chk = ch_lo; chk < ch_hi; ++chk) {
             const bool more = chk + 1 < ch_hi;
-            if (more) load_chunk();
+            if (more && !(Y5M_EXP & 4)) load_chunk();
             compute(cur);
             if constexpr (SB) {
                 __syncthreads();                     // every wave is done reading the only buffer
-                if (more) store_chunk(0);
+                if (more && !(Y5M_EXP & 2)) store_chunk(0);
                 __syncthreads();
             } else {
-                if (more) store_chunk(cur ^ 1);
+                if (more && !(Y5M_EXP & 2)) store_chunk(cur ^ 1);
                 __syncthreads();
                 cur ^= 1;
             }
@@ -389,10 +407,295 @@ __global__ __launch_bounds__(WN * WC * WK * 64) void wgrad_kernel(const WgradPar
     }
 }
 
+// ---- producer / consumer form (Y5M_WGRAD_PC=1; bf16, one tap per block, no K-waves) -----------------------------------
+// What the timing ablations of the kernel above say (tools/exp_wgrad.sh, 192 -> 192 @ 40x40, B=64, one block per CU:
+// 115 us): with the LDS stores removed 90 us, with the global loads removed as well 90, with the transposing reads replaced
+// by half as many ds_read_b128 115 (they are free), with the MFMAs removed 108 -- the wave's own staging (vmcnt wait, 9
+// ds_write_b128 at 13 cycles each, the second barrier) is the largest removable item, the matrix pipe is idle most of the
+// time. Here the staging moves to four PRODUCER waves (4-7: global -> VGPR -> LDS, one chunk ahead in registers, one more
+// in LDS) and waves 0-3 only read fragments and issue MFMAs; a SIMD holds one wave of each kind, so the producer's waits
+// and stores run next to the consumer's MFMAs instead of in front of them. Two LDS buffers, ONE barrier per chunk for all
+// eight waves (raw s_barrier behind lgkmcnt(0): a producer must not wait for the loads it has just issued).
+#define PC_BARRIER() \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier(); \
+    asm volatile("" ::: "memory");
+// scheduling pattern of one half-iteration of the consumer loop: MFMA i, then its share of the R fragment reads
+template <int I, int MF, int R>
+__device__ __forceinline__ void pc_interleave() {
+    if constexpr (I < MF) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int n = (I + 1) * R / MF - I * R / MF;
+        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+        pc_interleave<I + 1, MF, R>();
+    }
+}
+#if Y5M_EXP & 256
+#define PC_LOOP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define PC_LOOP_BARRIER() PC_BARRIER()
+#endif
+template <int WN, int WC, int CFR, int NFR>
+__global__ __launch_bounds__(512) void wgrad_pc_kernel(const WgradParams P) {
+    using T = bf16_t;
+    using C = WgCfg<T, WN, WC, 1, CFR, 1, NFR, 1>;
+    static_assert(C::THREADS == 256, "four consumer waves");
+    constexpr int KCH = C::KCH, CH = C::CH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int nblk = gridDim.x, hb = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = hb & 7;
+    int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hb >> 3);
+    const int tgroups = P.th * P.tw;
+    const int tap0 = bid % tgroups; bid /= tgroups;
+    const int ct = bid % P.tiles_c; bid /= P.tiles_c;
+    const int nt = bid % P.tiles_n;
+    const int ksp = bid / P.tiles_n;
+    const int n0 = nt * C::TN, c0 = ct * C::CBLK;
+    const int chunks_total = (P.M + KCH - 1) / KCH;
+    const int per = (chunks_total + P.ksplit - 1) / P.ksplit;
+    const int ch_lo = ksp * per, ch_hi = min(chunks_total, ch_lo + per);
+    if (ch_lo >= ch_hi) return;
+
+    if (producer) {
+        __builtin_amdgcn_s_setprio(3);          // the few producer instructions win the issue arbitration against the MFMA stream (+10 %)
+        const T* __restrict__ DY = reinterpret_cast<const T*>(P.dy);
+        const T* __restrict__ X = reinterpret_cast<const T*>(P.x);
+        constexpr unsigned OOB = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(DY), 0, (unsigned)((size_t)P.M * P.lddy * sizeof(T)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(X), 0, (unsigned)((size_t)P.B * P.Hin * P.Win * P.ldx * sizeof(T)), 0x00020000);
+        const bool lin = P.th == 1 && P.tw == 1 && P.sy == 1 && P.sx == 1 && P.dh0 == 0 && P.dw0 == 0 && P.Hin == P.Hg &&
+                         P.Win == P.Wg;
+        const int st = tid & 255;
+        const int pl = st / C::TPP, tp = st % C::TPP;
+        // two register sets: the chunk stored in iteration k was loaded in iteration k-2 (a full iteration of latency
+        // tolerance on top of the one the LDS double buffer gives)
+        u32x4 ry0[C::NLDY], rx0[C::NLDX], ry1[C::NLDY], rx1[C::NLDX];
+        unsigned yadd[C::NLDY], xadd[C::NLDX];
+#pragma unroll
+        for (int i = 0; i < C::NLDY; ++i) {
+            const int cc = tp + C::TPP * i;
+            yadd[i] = (cc < C::YCPR && n0 + cc * CH < P.N) ? (unsigned)((n0 + cc * CH) * sizeof(T)) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < C::NLDX; ++i) {
+            const int cc = tp + C::TPP * i;
+            const int chn = c0 + cc * CH;
+            xadd[i] = (cc < C::XCPR && chn < P.C) ? (unsigned)(chn * sizeof(T)) : OOB;
+        }
+        const int ta = tap0 / P.tw, tb = tap0 - ta * P.tw;
+        const int xdh = P.dh0 + ta * P.dhs, xdw = P.dw0 + tb * P.dws;
+        int gx = 0, gy = 0, gb = 0;
+        unsigned yrow, xrow;
+        {
+            const int m = ch_lo * KCH + pl;
+            yrow = (unsigned)m * (unsigned)(P.lddy * sizeof(T));
+            xrow = (unsigned)m * (unsigned)(P.ldx * sizeof(T));
+            const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+            int t;
+            fast_divmod(m, P.Wg, rcpW, t, gx);
+            fast_divmod(t, P.Hg, rcpH, gb, gy);
+        }
+        const int stepx = KCH % P.Wg, stepy = (KCH / P.Wg) % P.Hg, stepb = KCH / (P.Wg * P.Hg);
+        const unsigned ystep = (unsigned)(KCH * P.lddy * sizeof(T));
+        const unsigned ldxb = (unsigned)(P.ldx * sizeof(T));
+        auto load_chunk = [&](u32x4 (&ry)[C::NLDY], u32x4 (&rx)[C::NLDX]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < C::NLDY; ++i) ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, yrow + yadd[i], 0, 0);
+            if (lin) {
+#pragma unroll
+                for (int i = 0; i < C::NLDX; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xrow + xadd[i], 0, 0);
+            } else {
+                // one tap per block: the tap-shifted pixel and its bounds test are shared by the thread's X loads
+                const int iy = gy * P.sy + xdh, ix = gx * P.sx + xdw;
+                const bool in = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                const unsigned pix = __umul24((unsigned)(gb * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
+                const unsigned rowo = in ? __umul24(pix, ldxb) : OOB;
+#pragma unroll
+                for (int i = 0; i < C::NLDX; ++i)
+                    rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (rowo + xadd[i]) | ((rowo | xadd[i]) & OOB), 0, 0);   // either part out of range -> top bit set
+            }
+            yrow += ystep;
+            xrow += KCH * ldxb;
+            gx += stepx;
+            const int c1 = gx >= P.Wg ? 1 : 0;
+            gx -= c1 ? P.Wg : 0;
+            gy += stepy + c1;
+            const int c2 = gy >= P.Hg ? 1 : 0;
+            gy -= c2 ? P.Hg : 0;
+            gb += stepb + c2;
+        };
+        auto store_chunk = [&](int buf, const u32x4 (&ry)[C::NLDY], const u32x4 (&rx)[C::NLDX]) __attribute__((always_inline)) {
+            unsigned char* Ys = smem + buf * (C::YB + C::XB);
+            unsigned char* Xs = Ys + C::YB;
+#pragma unroll
+            for (int i = 0; i < C::NLDY; ++i) {
+                const int cc = tp + C::TPP * i;
+                if (cc < C::YCPR) *reinterpret_cast<u32x4*>(Ys + lds_chunk_off<true>(pl, cc, C::TN, C::LDY)) = ry[i];
+            }
+#pragma unroll
+            for (int i = 0; i < C::NLDX; ++i) {
+                const int cc = tp + C::TPP * i;
+                if (cc < C::XCPR) *reinterpret_cast<u32x4*>(Xs + lds_chunk_off<true>(pl, cc, C::TC, C::LDX)) = rx[i];
+            }
+        };
+        // chunk j of the range (j = 0, 1, ...) travels through register set j & 1 into LDS buffer j & 1
+        const int nch = ch_hi - ch_lo;
+        load_chunk(ry0, rx0);
+        if (1 < nch) load_chunk(ry1, rx1);
+        store_chunk(0, ry0, rx0);
+        if (2 < nch) load_chunk(ry0, rx0);
+        PC_BARRIER()
+        for (int j = 0; j < nch; j += 2) {
+            if (j + 1 < nch) {                        // consumers are on chunk j (buffer 0)
+                if (!(Y5M_EXP & 16)) store_chunk(1, ry1, rx1);
+                if (j + 3 < nch && !(Y5M_EXP & 32)) load_chunk(ry1, rx1);
+            }
+            PC_LOOP_BARRIER()
+            if (j + 1 >= nch) break;
+            if (j + 2 < nch) {                        // consumers are on chunk j + 1 (buffer 1)
+                if (!(Y5M_EXP & 16)) store_chunk(0, ry0, rx0);
+                if (j + 4 < nch && !(Y5M_EXP & 32)) load_chunk(ry0, rx0);
+            }
+            PC_LOOP_BARRIER()
+        }
+        return;
+    }
+
+    // ---- consumers ----
+    const int wn = wid % WN, wc = wid / WN;
+    f32x4 acc[NFR][CFR];
+#pragma unroll
+    for (int a = 0; a < NFR; ++a)
+#pragma unroll
+        for (int b = 0; b < CFR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane_off = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+    // Software pipeline over the K-steps (32 pixels each, two per chunk): the transposing reads of K-step t+1 are issued
+    // between the MFMAs of K-step t (second fragment register set), and the chunk barrier sits between the LAST READS of a
+    // chunk and its last MFMAs -- "buffer free" only needs the reads -- so the first reads of the next chunk fly under
+    // those MFMAs too. The loop body has no branch: behind the last chunk the other buffer is read once more and ignored.
+    static_assert(KCH == 64, "two K-steps per chunk");
+    if constexpr (NFR == 6 && CFR == 6) {
+        // 96 x 96 wave tile (192 x 192 block: a third less L2 -> LDS traffic and a third fewer fragment reads per MFMA than
+        // 192 x 96): 144 accumulator registers, so only the X fragments get a second register set; a dY fragment is
+        // re-read for the next K-step one row of MFMAs after its last use (the last row's fragment has two copies).
+        uint4 ya[6], ya5b, xbA[6], xbB[6];
+        auto frag = [&](const unsigned char* sub, uint4& r) __attribute__((always_inline)) {
+            const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
+            r = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+        };
+        auto rdx = [&](int buf, int ks, int b, uint4& r) __attribute__((always_inline)) {
+            frag(smem + buf * (C::YB + C::XB) + C::YB + (ks * (C::TC / 16) + wc * CFR + b) * WG_SUB, r);
+        };
+        auto rdy = [&](int buf, int ks, int a, uint4& r) __attribute__((always_inline)) {
+            frag(smem + buf * (C::YB + C::XB) + (ks * (C::TN / 16) + wn * NFR + a) * WG_SUB, r);
+        };
+        // MFMAs of the current K-step (X set A / B and the last dY fragment's copy by parity), reads of K-step (bufN, ksN)
+#define PC_HALF(XC, XN, Y5C, Y5N, bufN, ksN) \
+_Pragma("unroll") \
+        for (int a = 0; a < 6; ++a) { \
+_Pragma("unroll") \
+            for (int b = 0; b < 6; ++b) \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a == 5 ? Y5C : ya[a]), \
+                                                                    __builtin_bit_cast(bf16x8_t, XC[b]), acc[a][b], 0, 0, 0); \
+            rdx(bufN, ksN, a, XN[a]); \
+            if (a == 0) rdy(bufN, ksN, 5, Y5N); else rdy(bufN, ksN, a - 1, ya[a - 1]); \
+        } \
+_Pragma("unroll") \
+        for (int a = 0; a < 6; ++a) { \
+_Pragma("unroll") \
+            for (int i = 0; i < 4; ++i) { \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+            } \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); \
+        }
+        PC_BARRIER()
+#pragma unroll
+        for (int b = 0; b < 6; ++b) rdx(0, 0, b, xbA[b]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rdy(0, 0, a, ya[a]);
+        int cur = 0;
+        for (int chk = ch_lo; chk < ch_hi; ++chk) {
+            PC_HALF(xbA, xbB, ya[5], ya5b, cur, 1)
+            PC_LOOP_BARRIER()                          // every read of this chunk has returned: its buffer is free
+            PC_HALF(xbB, xbA, ya5b, ya[5], cur ^ 1, 0)
+            cur ^= 1;
+        }
+#undef PC_HALF
+    } else {
+    uint4 ya0[NFR], xb0[CFR], ya1[NFR], xb1[CFR];
+    auto rd = [&](int buf, int ks, uint4 (&yr)[NFR], uint4 (&xr)[CFR]) __attribute__((always_inline)) {
+        const unsigned char* Ys = smem + buf * (C::YB + C::XB);
+        const unsigned char* Xs = Ys + C::YB;
+#pragma unroll
+        for (int b = 0; b < CFR; ++b) {
+            const unsigned char* sub = Xs + (ks * (C::TC / 16) + wc * CFR + b) * WG_SUB;
+            const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
+            xr[b] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+        }
+#pragma unroll
+        for (int a = 0; a < NFR; ++a) {
+            const unsigned char* sub = Ys + (ks * (C::TN / 16) + wn * NFR + a) * WG_SUB;
+            const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
+            yr[a] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+        }
+    };
+    auto mm = [&](const uint4 (&yr)[NFR], const uint4 (&xr)[CFR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < NFR; ++a)
+#pragma unroll
+            for (int b = 0; b < CFR; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, yr[a]),
+                                                                    __builtin_bit_cast(bf16x8_t, xr[b]), acc[a][b], 0, 0, 0);
+    };
+    // issue order of one half-iteration: MFMA, then its share of the 2 * (NFR + CFR) reads of the next K-step
+    auto interleave = [&]() __attribute__((always_inline)) { pc_interleave<0, NFR * CFR, 2 * (NFR + CFR)>(); };
+    PC_BARRIER()
+    rd(0, 0, ya0, xb0);
+    int cur = 0;
+    for (int chk = ch_lo; chk < ch_hi; ++chk) {
+        if (!(Y5M_EXP & 128)) rd(cur, 1, ya1, xb1);
+        if (!(Y5M_EXP & 64)) mm(ya0, xb0);
+        if (!(Y5M_EXP & (64 | 128))) interleave();
+        PC_LOOP_BARRIER()                              // every read of this chunk has returned: its buffer is free
+        if (!(Y5M_EXP & 128)) rd(cur ^ 1, 0, ya0, xb0);
+        if (!(Y5M_EXP & 64)) mm(ya1, xb1);
+        if (!(Y5M_EXP & (64 | 128))) interleave();
+        cur ^= 1;
+    }
+    }
+    {
+        const bool slices = P.slices_cap > 0;
+        const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < NFR; ++a)
+#pragma unroll
+            for (int b = 0; b < CFR; ++b) {
+                const int c = c0 + (wc * CFR + b) * 16 + i;
+                if (c >= P.C) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * (16 * NFR) + a * 16 + g * 4 + r;
+                    if (n < P.N) {
+                        float* d = P.dwgt + (size_t)n * P.lddw + tap0 * P.C + c;
+                        if (slices) d[(size_t)ksp * P.N * P.lddw] = acc[a][b][r];
+                        else if (!(Y5M_EXP & 512) || acc[a][b][r] == 12345.678f) atomicAdd(d, acc[a][b][r]);
+                    }
+                }
+            }
+    }
+}
+
 static thread_local bool g_plan_only = false;   // y5m_wgrad_slices: run the dispatch + split-K sizing, launch nothing
 static thread_local int g_plan_slices = 0;
 
-template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3, int KX = 1, bool FP = false>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3, int KX = 1, bool FP = false, bool PC = false>
 static int launch_wgrad(WgradParams& P, hipStream_t st) {
     using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR, KX>;
     P.tiles_n = (P.N + C::TN - 1) / C::TN;
@@ -413,7 +716,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         static int sbk = -1;
         if (sbk < 0) { const char* e = getenv("Y5M_WGRAD_SB"); sbk = e ? atoi(e) : 1; }
         const int per_cu = (int)((160 * 1024) / (2 * (size_t)(C::YB + C::XB)));
-        const int resident = 256 * ((NFR == 6 || C::THREADS > 256) ? 2 : (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu)));
+        const int resident = 256 * ((NFR == 6 || C::THREADS > 256 || PC) ? 2 : (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu)));
         int ks;
         if (target > 0) ks = (target + base - 1) / base;
         else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
@@ -435,7 +738,8 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
             // +0.1 / +0.35 / +0.5 ms per step
             static int res_pct = -1;
             if (res_pct < 0) { const char* e = getenv("Y5M_WGRAD_RES_PCT"); res_pct = e ? atoi(e) : 50; }
-            ks = (sbk && NFR != 6 && C::THREADS == 256 ? 1024 : resident) * res_pct / 100 / base;   // floor: never more blocks than fit at once (SB: 4 per CU)
+            ks = (sbk && NFR != 6 && C::THREADS == 256 && !PC ? 1024 : resident) * res_pct / 100 / base;
+            if (PC && NFR == 6 && CFR == 6) ks = 256 / base;     // 104 KB of LDS: one block per CU IS the resident round   // floor: never more blocks than fit at once (SB: 4 per CU)
         }
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
@@ -461,6 +765,18 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, true, KX, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false, KX, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr = true;
+    }
+    if constexpr (PC && sizeof(T) == 2 && TPB == 1 && WK == 1 && KX == 1) {
+        auto pk = wgrad_pc_kernel<WN, WC, CFR, NFR>;
+        static bool pattr = false;
+        if (!pattr) {
+            (void)hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (size_t)(C::YB + C::XB)));
+            pattr = true;
+        }
+        Y5M_NAME_ONLY(Y5M_OK, "wgrad_pc_kernel<%d,%d,%d,%d>", WN, WC, CFR, NFR);
+        hipLaunchKernelGGL(pk, dim3(grid), dim3(512), 2 * (size_t)(C::YB + C::XB), st, P);
+        Y5M_CHECK_LAUNCH("wgrad_pc_kernel");
+        return Y5M_OK;
     }
     Y5M_NAME_ONLY(Y5M_OK, "wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WN, WC, WK, CFR, TPB, NFR, (int)use_sb, KX, (int)FP);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
@@ -512,6 +828,17 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
         if (big && P.N % 192 == 0 && fp == 1) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, true>(P, st);
         if (big && P.N % 192 == 0 && fp == 2) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 2, true>(P, st);
         if (big && P.N % 192 == 0 && fp == 3) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 2, false>(P, st);
+    }
+    if constexpr (sizeof(T) == 2) {
+        // Y5M_WGRAD_PC: producer / consumer form (bit 0: the 192 x 96 tile, bit 1: the 96 x 96 tile; bit 2: also pointwise layers;
+        // bit 3: a 192 x 192 tile where both channel counts allow it)
+        static int pc = -1;
+        if (pc < 0) { const char* e = getenv("Y5M_WGRAD_PC"); pc = e ? atoi(e) : 0; }
+        if (pc && P.slices_cap <= 0 && (taps > 1 || (pc & 4))) {
+            if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, true>(P, st);
+            if ((pc & 1) && big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, true>(P, st);
+            if ((pc & 2) && !(big && P.N % 192 == 0)) return launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, true>(P, st);
+        }
     }
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
     return launch_wgrad<T, 2, 2, 1, 3>(P, st);                     // 96 x 96
