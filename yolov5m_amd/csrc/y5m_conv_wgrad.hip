@@ -692,10 +692,216 @@ _Pragma("unroll") \
     }
 }
 
+// ---- producer / consumer form with LDS-DMA staging (Y5M_WGRAD_PC bit 4; bf16, one tap per block, full channel tiles) ----
+// Same consumers as wgrad_pc_kernel; the NPW producer waves issue `buffer_load_dwordx4 ... lds` straight into the
+// [32 pixel][16 channel] sub-tiles (one DMA instruction = one 1 KiB sub-tile: lane l supplies the address of pixel l >> 1,
+// channel half l & 1, and the hardware writes LDS[m0 + 16 l]; out-of-image taps and the pixel tail are offsets >= num_records
+// = zeros). No staging registers, no ds_write; THREE LDS buffers: in iteration j the producers issue chunk j + 2 and wait
+// (counted vmcnt) for chunk j + 1, so a DMA has a whole iteration to land. Producer wave (g, h): pixel group g (32 of the
+// chunk's 64 pixels), the h-th share of the dY and X sub-tiles.
+__device__ __forceinline__ void wg_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+template <int WN, int WC, int CFR, int NFR, int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW) void wgrad_dma_kernel(const WgradParams P) {
+    using T = bf16_t;
+    using C = WgCfg<T, WN, WC, 1, CFR, 1, NFR, 1>;
+    static_assert(C::THREADS == 256, "four consumer waves");
+    constexpr int KCH = C::KCH;
+    static_assert(KCH == 64, "two 32-pixel groups per chunk");
+    constexpr int BUF = C::YB + C::XB, NB = 3;
+    constexpr int YS = C::TN / 16, XS = C::TC / 16;       // sub-tiles per 32-pixel group
+    constexpr int SH = NPW / 2;                           // producer waves per pixel group
+    static_assert(NPW == 2 || NPW == 4, "producer waves");
+    static_assert(YS % SH == 0 && XS % SH == 0, "sub-tiles split evenly");
+    constexpr int NDY = YS / SH, NDX = XS / SH, NDW = NDY + NDX;      // DMA instructions per producer wave and chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int nblk = gridDim.x, hb = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = hb & 7;
+    int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hb >> 3);
+    const int tgroups = P.th * P.tw;
+    const int tap0 = bid % tgroups; bid /= tgroups;
+    const int ct = bid % P.tiles_c; bid /= P.tiles_c;
+    const int nt = bid % P.tiles_n;
+    const int ksp = bid / P.tiles_n;
+    const int n0 = nt * C::TN, c0 = ct * C::CBLK;
+    const int chunks_total = (P.M + KCH - 1) / KCH;
+    const int per = (chunks_total + P.ksplit - 1) / P.ksplit;
+    const int ch_lo = ksp * per, ch_hi = min(chunks_total, ch_lo + per);
+    if (ch_lo >= ch_hi) return;
+    const int nch = ch_hi - ch_lo;
+
+    if (producer) {
+        __builtin_amdgcn_s_setprio(3);
+        constexpr unsigned OOB = 0x80000000u;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(P.dy), 0, (unsigned)((size_t)P.M * P.lddy * sizeof(T)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(P.x), 0, (unsigned)((size_t)P.B * P.Hin * P.Win * P.ldx * sizeof(T)), 0x00020000);
+        const int pw = wid - 4, g = pw % 2, h = pw / 2;
+        const int px = lane >> 1, half = lane & 1;
+        const int ta = tap0 / P.tw, tb = tap0 - ta * P.tw;
+        const int xdh = P.dh0 + ta * P.dhs, xdw = P.dw0 + tb * P.dws;
+        const unsigned ldxb = (unsigned)(P.ldx * sizeof(T)), ldyb = (unsigned)(P.lddy * sizeof(T));
+        // this lane's pixel of the chunk the state points at: m = chunk * 64 + g * 32 + px
+        int gx, gy, gb;
+        unsigned yoff;                                        // dY: row m, this wave's first sub-tile, this lane's half
+        {
+            const int m = ch_lo * KCH + g * 32 + px;
+            yoff = (unsigned)m * ldyb + (unsigned)((n0 + h * NDY * 16 + half * 8) * sizeof(T));
+            const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+            int t;
+            fast_divmod(m, P.Wg, rcpW, t, gx);
+            fast_divmod(t, P.Hg, rcpH, gb, gy);
+        }
+        const unsigned xch = (unsigned)((c0 + h * NDX * 16 + half * 8) * sizeof(T));
+        const int stepx = KCH % P.Wg, stepy = (KCH / P.Wg) % P.Hg, stepb = KCH / (P.Wg * P.Hg);
+        // LDS address of this wave's first dY / X sub-tile inside a buffer
+        const unsigned ydst = lds0 + (unsigned)((g * YS + h * NDY) * WG_SUB);
+        const unsigned xdst = lds0 + (unsigned)(C::YB + (g * XS + h * NDX) * WG_SUB);
+        auto issue = [&](unsigned boff) __attribute__((always_inline)) {     // the chunk the state points at -> buffer at boff; advance
+            const int iy = gy * P.sy + xdh, ix = gx * P.sx + xdw;
+            const bool in = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            const unsigned pix = __umul24((unsigned)(gb * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
+            const unsigned xoff = in ? __umul24(pix, ldxb) + xch : OOB;
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) wg_dma16(rs_y, yoff + (unsigned)(i * 32), ydst + boff + (unsigned)(i * WG_SUB));
+#pragma unroll
+            for (int i = 0; i < NDX; ++i) wg_dma16(rs_x, xoff + (unsigned)(i * 32), xdst + boff + (unsigned)(i * WG_SUB));
+            yoff += (unsigned)KCH * ldyb;
+            gx += stepx;
+            const int c1 = gx >= P.Wg ? 1 : 0;
+            gx -= c1 ? P.Wg : 0;
+            gy += stepy + c1;
+            const int c2 = gy >= P.Hg ? 1 : 0;
+            gy -= c2 ? P.Hg : 0;
+            gb += stepb + c2;
+        };
+        // (chunks behind the block's range are issued as well -- the loop has no branch; behind the tensor they read as zeros)
+        issue(0u);
+        issue((unsigned)BUF);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDW) : "memory");
+        PC_BARRIER()
+        unsigned nb = 2u * BUF;                                // buffer of chunk j + 2
+        for (int j = 0; j < nch; ++j) {
+            issue(nb);
+            nb = nb == 2u * BUF ? 0u : nb + (unsigned)BUF;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDW) : "memory");     // chunk j + 1 has landed
+            PC_BARRIER()
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing may still be writing this workgroup's LDS when it ends
+        return;
+    }
+
+    // ---- consumers (wgrad_pc_kernel's loops over three buffers) ----
+    const int wn = wid % WN, wc = wid / WN;
+    f32x4 acc[NFR][CFR];
+#pragma unroll
+    for (int a = 0; a < NFR; ++a)
+#pragma unroll
+        for (int b = 0; b < CFR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane_off = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+    auto frag = [&](const unsigned char* sub, uint4& r) __attribute__((always_inline)) {
+        const s16x4_t lo = tr_read(sub, lane_off, 0), hi = tr_read(sub, lane_off, 1);
+        r = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+    };
+    auto rdx = [&](unsigned boff, int ks, int b, uint4& r) __attribute__((always_inline)) {
+        frag(smem + boff + C::YB + (ks * XS + wc * CFR + b) * WG_SUB, r);
+    };
+    auto rdy = [&](unsigned boff, int ks, int a, uint4& r) __attribute__((always_inline)) {
+        frag(smem + boff + (ks * YS + wn * NFR + a) * WG_SUB, r);
+    };
+    unsigned cur = 0u;
+    if constexpr (NFR == 6 && CFR == 6) {
+        uint4 ya[6], ya5b, xbA[6], xbB[6];
+#define DM_HALF(XC, XN, Y5C, Y5N, boffN, ksN) \
+_Pragma("unroll") \
+        for (int a = 0; a < 6; ++a) { \
+_Pragma("unroll") \
+            for (int b = 0; b < 6; ++b) \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a == 5 ? Y5C : ya[a]), \
+                                                                    __builtin_bit_cast(bf16x8_t, XC[b]), acc[a][b], 0, 0, 0); \
+            rdx(boffN, ksN, a, XN[a]); \
+            if (a == 0) rdy(boffN, ksN, 5, Y5N); else rdy(boffN, ksN, a - 1, ya[a - 1]); \
+        } \
+_Pragma("unroll") \
+        for (int a = 0; a < 6; ++a) { \
+_Pragma("unroll") \
+            for (int i = 0; i < 4; ++i) { \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+            } \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); \
+        }
+        PC_BARRIER()
+#pragma unroll
+        for (int b = 0; b < 6; ++b) rdx(0u, 0, b, xbA[b]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rdy(0u, 0, a, ya[a]);
+        for (int j = 0; j < nch; ++j) {
+            const unsigned nxt = cur == 2u * BUF ? 0u : cur + (unsigned)BUF;
+            DM_HALF(xbA, xbB, ya[5], ya5b, cur, 1)
+            PC_BARRIER()
+            DM_HALF(xbB, xbA, ya5b, ya[5], nxt, 0)
+            cur = nxt;
+        }
+#undef DM_HALF
+    } else {
+        uint4 ya0[NFR], xb0[CFR], ya1[NFR], xb1[CFR];
+        auto rd = [&](unsigned boff, int ks, uint4 (&yr)[NFR], uint4 (&xr)[CFR]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < CFR; ++b) rdx(boff, ks, b, xr[b]);
+#pragma unroll
+            for (int a = 0; a < NFR; ++a) rdy(boff, ks, a, yr[a]);
+        };
+        auto mm = [&](const uint4 (&yr)[NFR], const uint4 (&xr)[CFR]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < NFR; ++a)
+#pragma unroll
+                for (int b = 0; b < CFR; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, yr[a]),
+                                                                        __builtin_bit_cast(bf16x8_t, xr[b]), acc[a][b], 0, 0, 0);
+        };
+        PC_BARRIER()
+        rd(0u, 0, ya0, xb0);
+        for (int j = 0; j < nch; ++j) {
+            const unsigned nxt = cur == 2u * BUF ? 0u : cur + (unsigned)BUF;
+            rd(cur, 1, ya1, xb1);
+            mm(ya0, xb0);
+            pc_interleave<0, NFR * CFR, 2 * (NFR + CFR)>();
+            PC_BARRIER()
+            rd(nxt, 0, ya0, xb0);
+            mm(ya1, xb1);
+            pc_interleave<0, NFR * CFR, 2 * (NFR + CFR)>();
+            cur = nxt;
+        }
+    }
+    {
+        const int i = lane & 15, gq = lane >> 4;
+#pragma unroll
+        for (int a = 0; a < NFR; ++a)
+#pragma unroll
+            for (int b = 0; b < CFR; ++b) {
+                const int c = c0 + (wc * CFR + b) * 16 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * (16 * NFR) + a * 16 + gq * 4 + r;
+                    atomicAdd(P.dwgt + (size_t)n * P.lddw + tap0 * P.C + c, acc[a][b][r]);
+                }
+            }
+    }
+}
+
 static thread_local bool g_plan_only = false;   // y5m_wgrad_slices: run the dispatch + split-K sizing, launch nothing
 static thread_local int g_plan_slices = 0;
 
-template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3, int KX = 1, bool FP = false, bool PC = false>
+template <typename T, int WN, int WC, int WK, int CFR, int TPB = 1, int NFR = 3, int KX = 1, bool FP = false, int PC = 0>
 static int launch_wgrad(WgradParams& P, hipStream_t st) {
     using C = WgCfg<T, WN, WC, WK, CFR, TPB, NFR, KX>;
     P.tiles_n = (P.N + C::TN - 1) / C::TN;
@@ -739,7 +945,12 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
             static int res_pct = -1;
             if (res_pct < 0) { const char* e = getenv("Y5M_WGRAD_RES_PCT"); res_pct = e ? atoi(e) : 50; }
             ks = (sbk && NFR != 6 && C::THREADS == 256 && !PC ? 1024 : resident) * res_pct / 100 / base;
-            if (PC && NFR == 6 && CFR == 6) ks = 256 / base;     // 104 KB of LDS: one block per CU IS the resident round   // floor: never more blocks than fit at once (SB: 4 per CU)
+            if (PC && NFR == 6 && CFR == 6) ks = 256 / base;     // 104 KB of LDS: one block per CU IS the resident round
+            if (PC >= 2 && NFR == 6) {                            // three LDS buffers (117 / 156 KB): one block per CU
+                static int dmab = -1;                             // Y5M_WGRAD_DMA_BLOCKS: CUs the launch may own (the rest stay with the main stream)
+                if (dmab < 0) { const char* e = getenv("Y5M_WGRAD_DMA_BLOCKS"); dmab = e ? atoi(e) : 256; }
+                ks = dmab / base;
+            }   // floor: never more blocks than fit at once (SB: 4 per CU)
         }
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
@@ -766,7 +977,20 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WN, WC, WK, CFR, TPB, NFR, false, KX, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr = true;
     }
-    if constexpr (PC && sizeof(T) == 2 && TPB == 1 && WK == 1 && KX == 1) {
+    if constexpr (PC >= 2 && sizeof(T) == 2 && TPB == 1 && WK == 1 && KX == 1) {
+        constexpr int NPW = PC == 2 ? 4 : 2;
+        auto dk = wgrad_dma_kernel<WN, WC, CFR, NFR, NPW>;
+        static bool dattr = false;
+        if (!dattr) {
+            (void)hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(C::YB + C::XB)));
+            dattr = true;
+        }
+        Y5M_NAME_ONLY(Y5M_OK, "wgrad_dma_kernel<%d,%d,%d,%d,%d>", WN, WC, CFR, NFR, NPW);
+        hipLaunchKernelGGL(dk, dim3(grid), dim3(256 + 64 * NPW), 3 * (size_t)(C::YB + C::XB), st, P);
+        Y5M_CHECK_LAUNCH("wgrad_dma_kernel");
+        return Y5M_OK;
+    }
+    if constexpr (PC == 1 && sizeof(T) == 2 && TPB == 1 && WK == 1 && KX == 1) {
         auto pk = wgrad_pc_kernel<WN, WC, CFR, NFR>;
         static bool pattr = false;
         if (!pattr) {
@@ -831,13 +1055,23 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     }
     if constexpr (sizeof(T) == 2) {
         // Y5M_WGRAD_PC: producer / consumer form (bit 0: the 192 x 96 tile, bit 1: the 96 x 96 tile; bit 2: also pointwise layers;
-        // bit 3: a 192 x 192 tile where both channel counts allow it)
+        // bit 3: a 192 x 192 tile where both channel counts allow it; bits 4 / 5: wgrad_dma_kernel with 4 / 2 producer waves)
         static int pc = -1;
         if (pc < 0) { const char* e = getenv("Y5M_WGRAD_PC"); pc = e ? atoi(e) : 0; }
+        if ((pc & 48) && P.slices_cap <= 0 && (taps > 1 || (pc & 4)) && P.C % 16 == 0 && P.N % 16 == 0) {
+            // bits 4 / 5: LDS-DMA producers (4 / 2 producer waves); full channel tiles only
+            const bool two = (pc & 32) != 0;
+            if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0)
+                return two ? launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 3>(P, st) : launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 2>(P, st);
+            if ((pc & 1) && big && P.N % 192 == 0 && P.C % 96 == 0)
+                return two ? launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, 3>(P, st) : launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, 2>(P, st);
+            if ((pc & 2) && P.N % 96 == 0 && P.C % 96 == 0 && !(big && P.N % 192 == 0))
+                return two ? launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, 3>(P, st) : launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, 2>(P, st);
+        }
         if (pc && P.slices_cap <= 0 && (taps > 1 || (pc & 4))) {
-            if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, true>(P, st);
-            if ((pc & 1) && big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, true>(P, st);
-            if ((pc & 2) && !(big && P.N % 192 == 0)) return launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, true>(P, st);
+            if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 1>(P, st);
+            if ((pc & 1) && big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, 1>(P, st);
+            if ((pc & 2) && !(big && P.N % 192 == 0)) return launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, 1>(P, st);
         }
     }
     if (big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6>(P, st);
