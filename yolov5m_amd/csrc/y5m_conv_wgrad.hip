@@ -1058,7 +1058,10 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
         // bit 3: a 192 x 192 tile where both channel counts allow it; bits 4 / 5: wgrad_dma_kernel with 4 / 2 producer waves)
         static int pc = -1;
         if (pc < 0) { const char* e = getenv("Y5M_WGRAD_PC"); pc = e ? atoi(e) : 0; }
-        if ((pc & 48) && P.slices_cap <= 0 && (taps > 1 || (pc & 4)) && P.C % 16 == 0 && P.N % 16 == 0) {
+        static int pcsel = -1;              // Y5M_WGRAD_PC_SEL: 0 = every eligible layer, 1 = stride-2 layers only, 2 = C >= 384 only, 3 = either
+        if (pcsel < 0) { const char* e = getenv("Y5M_WGRAD_PC_SEL"); pcsel = e ? atoi(e) : 0; }
+        const bool sel = pcsel == 0 || ((pcsel & 1) && P.sy == 2) || ((pcsel & 2) && P.C >= 384);
+        if (sel && (pc & 48) && P.slices_cap <= 0 && (taps > 1 || (pc & 4)) && P.C % 16 == 0 && P.N % 16 == 0) {
             // bits 4 / 5: LDS-DMA producers (4 / 2 producer waves); full channel tiles only
             const bool two = (pc & 32) != 0;
             if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0)
@@ -1068,7 +1071,7 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
             if ((pc & 2) && P.N % 96 == 0 && P.C % 96 == 0 && !(big && P.N % 192 == 0))
                 return two ? launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, 3>(P, st) : launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, 2>(P, st);
         }
-        if (pc && P.slices_cap <= 0 && (taps > 1 || (pc & 4))) {
+        if (sel && pc && P.slices_cap <= 0 && (taps > 1 || (pc & 4))) {
             if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 1>(P, st);
             if ((pc & 1) && big && P.N % 192 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, 1>(P, st);
             if ((pc & 2) && !(big && P.N % 192 == 0)) return launch_wgrad<T, 2, 2, 1, 3, 1, 3, 1, false, 1>(P, st);
