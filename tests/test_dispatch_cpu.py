@@ -1,0 +1,110 @@
+"""Which kernel instantiation the library dispatches each YOLOv5m layer family to (y5m_conv_kernel_name /
+y5m_wgrad_kernel_name run the dispatch and launch nothing, so this needs no GPU). Pins the defaults the measurements in
+DESIGN.md sections 4-5 refer to (B=64 @ 640^2 shapes, bf16), and the knob-selected weight-gradient forms in a child process
+(every knob is read once per process). Layer shapes: reference model.py:12-28 (CBL), :60-118 (C3 / Bottleneck)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+from yolov5m_amd import _lib
+from yolov5m_amd._lib import BF16, EPI_DGRAD, EPI_RAW_STATS, ConvArgs, WgradArgs
+
+_rup = lambda x, m: (x + m - 1) // m * m
+_PTR = 16          # any non-null value: nothing is dereferenced in name-only mode
+
+
+def _conv_name(B, Cin, H, W, Cout, k, s, epi):
+    L = _lib.lib()
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    a = ConvArgs()
+    a.zeros = a.inp = a.w = a.out = a.stats = _PTR
+    a.B, a.Hin, a.Win, a.ldin, a.Hg, a.Wg, a.sy, a.sx = B, H, W, Cin, Ho, Wo, s, s
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -p, 1, -p, 1
+    K = k * k * Cin
+    a.Cin, a.K, a.N, a.M = Cin, K, Cout, B * Ho * Wo
+    a.Kp = _rup(K, 64) + (64 * ((Cin + 63) // 64) if k == 3 else 0)      # room for the halo kernel's last weight unit
+    a.Hout, a.Wout, a.ldout, a.osy, a.osx = Ho, Wo, Cout, 1, 1
+    a.Np = _rup(Cout, 192)
+    a.epi = epi
+    buf = ctypes.create_string_buffer(192)
+    _lib.check(L.y5m_conv_kernel_name(ctypes.byref(a), BF16, buf, 192), "y5m_conv_kernel_name")
+    return buf.value.decode()
+
+
+def _wgrad_name(B, Cin, H, W, Cout, k, s):
+    L = _lib.lib()
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    a = WgradArgs()
+    a.zeros = a.dy = a.x = a.dwgt = _PTR
+    a.B, a.Hin, a.Win, a.ldx, a.Hg, a.Wg, a.sy, a.sx = B, H, W, Cin, Ho, Wo, s, s
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -p, 1, -p, 1
+    a.C, a.N, a.M, a.lddy, a.lddw, a.ksplit = Cin, Cout, B * Ho * Wo, Cout, k * k * Cin, 0
+    buf = ctypes.create_string_buffer(192)
+    _lib.check(L.y5m_wgrad_kernel_name(ctypes.byref(a), BF16, buf, 192), "y5m_wgrad_kernel_name")
+    return buf.value.decode()
+
+
+_DEFAULT_ENV = not any(k.startswith("Y5M_CONV") or k.startswith("Y5M_WGRAD") for k in os.environ)
+
+CONV_DEFAULTS = [
+    # B, Cin, H, W, Cout, k, s -> forward (raw + statistics), data gradient
+    ((64, 192, 40, 40, 192, 3, 1), "conv_halo_kernel<6,0>", "conv_halo_kernel<6,3>"),
+    ((64, 384, 20, 20, 384, 3, 1), "conv_halo_kernel<6,0>", "conv_halo_kernel<6,3>"),
+    ((64, 96, 80, 80, 96, 3, 1), "conv_igemm_kernel<bf16,2,2,4,3,0,0>", "conv_igemm_kernel<bf16,2,2,4,3,0,0>"),
+    ((64, 96, 160, 160, 192, 3, 2), "conv_igemm_kernel<bf16,2,4,4,3,0,0>", None),
+    ((64, 96, 80, 80, 96, 1, 1), "conv_pw_kernel<6,3,0,0,0,0>", "conv_pw_kernel<6,3,3,0,0,0>"),
+    ((64, 48, 160, 160, 48, 3, 1), "conv_pw_kernel<3,14,0,0,0,48>", "conv_pw_kernel<3,14,3,0,0,48>"),
+    ((64, 384, 40, 40, 384, 1, 1), "conv_gemm8_kernel<0>", "conv_igemm_kernel<bf16,2,4,4,3,0,0>"),
+    ((64, 768, 20, 20, 768, 1, 1), "conv_gemm8_kernel<0>", "conv_igemm_kernel<bf16,2,4,4,3,0,0>"),
+]
+
+WGRAD_DEFAULTS = [
+    ((64, 192, 40, 40, 192, 3, 1), "wgrad_kernel<bf16,2,2,1,3,1,6,1,1,0>"),       # the roofline headline of bench.py
+    ((64, 384, 40, 40, 768, 3, 2), "wgrad_kernel<bf16,2,2,1,3,1,6,1,1,0>"),
+    ((64, 96, 80, 80, 96, 3, 1), "wgrad_kernel<bf16,2,2,1,3,1,3,1,1,0>"),
+    ((64, 48, 160, 160, 96, 3, 2), "wgrad_kernel<bf16,2,1,2,3,1,3,1,1,0>"),
+    ((64, 16, 320, 320, 48, 3, 1), "wgrad_kernel<bf16,1,1,4,9,9,3,0,1,0>"),        # stem: all nine taps in one block
+    ((64, 384, 20, 20, 384, 1, 1), "wgrad_kernel<bf16,2,2,1,3,1,6,1,1,0>"),
+]
+
+
+@pytest.mark.skipif(not _DEFAULT_ENV, reason="a Y5M_CONV* / Y5M_WGRAD* knob is set")
+@pytest.mark.parametrize("case,fwd,dgrad", CONV_DEFAULTS)
+def test_conv_default_dispatch(case, fwd, dgrad):
+    assert _conv_name(*case, EPI_RAW_STATS) == fwd
+    if dgrad is not None:
+        assert _conv_name(*case, EPI_DGRAD) == dgrad
+
+
+@pytest.mark.skipif(not _DEFAULT_ENV, reason="a Y5M_CONV* / Y5M_WGRAD* knob is set")
+@pytest.mark.parametrize("case,want", WGRAD_DEFAULTS)
+def test_wgrad_default_dispatch(case, want):
+    assert _wgrad_name(*case) == want
+
+
+# Y5M_WGRAD_PC -> expected names for (192 -> 192 3x3), (96 -> 96 3x3), (384 -> 768 3x3 stride 2), (48 -> 96: never taken)
+WGRAD_FORMS = {
+    "9": ("wgrad_pc_kernel<2,2,6,6>", "wgrad_kernel<bf16,2,2,1,3,1,3,1,1,0>", "wgrad_pc_kernel<2,2,6,6>"),
+    "3": ("wgrad_pc_kernel<2,2,3,6>", "wgrad_pc_kernel<2,2,3,3>", "wgrad_pc_kernel<2,2,3,6>"),
+    "57": ("wgrad_dma_kernel<2,2,6,6,2>", "wgrad_kernel<bf16,2,2,1,3,1,3,1,1,0>", "wgrad_dma_kernel<2,2,6,6,2>"),
+    "19": ("wgrad_dma_kernel<2,2,3,6,4>", "wgrad_dma_kernel<2,2,3,3,4>", "wgrad_dma_kernel<2,2,3,6,4>"),
+}
+
+
+@pytest.mark.parametrize("bits", sorted(WGRAD_FORMS))
+def test_wgrad_form_knob_dispatch(bits):
+    code = ("import sys; sys.path.insert(0, %r); import tests.test_dispatch_cpu as t; "
+            "print('|'.join(t._wgrad_name(*c) for c in [(64,192,40,40,192,3,1),(64,96,80,80,96,3,1),(64,384,40,40,768,3,2),"
+            "(64,48,160,160,96,3,2)]))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("Y5M_WGRAD")}
+    env["Y5M_WGRAD_PC"] = bits
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = r.stdout.strip().splitlines()[-1].split("|")
+    assert tuple(got[:3]) == WGRAD_FORMS[bits], got
+    assert got[3] == "wgrad_kernel<bf16,2,1,2,3,1,3,1,1,0>"          # 48 input channels: the small-channel tile, always
