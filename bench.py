@@ -93,6 +93,30 @@ def cpu_baseline(B=4, size=640, steps=3):
                       f"({os.cpu_count()} logical CPUs)"}
 
 
+def wgrad_forms_leg():
+    """The weight-gradient kernel forms ALONE on the chip (tools/conv_bench.py in child processes: the form is chosen by
+    Y5M_WGRAD_PC, read once per process): the default 4-wave wgrad_kernel -- the roofline headline above, measured there
+    INSIDE the step -- and wgrad_dma_kernel (LDS-DMA producer waves + software-pipelined consumer waves), which is faster
+    alone and slower inside the overlapped step. HIP events around 50 launches, B=64, bf16."""
+    import re
+    import subprocess
+    shapes = {"192->192 3x3 @40x40": "64 192 40 40 192 3 1 50", "384->768 3x3 stride 2 @40x40": "64 384 40 40 768 3 2 50"}
+    out = {}
+    for form, pc in (("wgrad_kernel (default)", "0"), ("wgrad_dma_kernel (Y5M_WGRAD_PC=57)", "57")):
+        for name, args_ in shapes.items():
+            try:
+                env = dict(os.environ, Y5M_WGRAD_PC=pc)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_bench.py"), "wgrad"] + args_.split(),
+                                   env=env, capture_output=True, text=True, timeout=180)
+                m = re.search(r"([0-9.]+) us\s+([0-9.]+) TF/s", r.stdout)
+                if m:
+                    out.setdefault(form, {})[name] = {"us": float(m.group(1)), "TFLOPs": float(m.group(2)),
+                                                      "frac": round(float(m.group(2)) / PEAK_BF16_TFLOPS, 4)}
+            except Exception:
+                pass
+    return out
+
+
 def first_loss_check(first_loss, B, S, rank):
     """the first step's ComputeLoss next to the REAL reference's f32 value for the same inputs and initial weights
     (tests/golden/g13_precision.npz, made by tests/golden/make_golden.py from /root/reference; B = 64 @ 640x640, rank 0)"""
@@ -363,6 +387,11 @@ def main():
                                          "frac": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
             },
         }
+    if world == 1 and not args.no_roofline:
+        try:
+            out["roofline"]["wgrad_forms_alone_on_the_chip"] = wgrad_forms_leg()
+        except Exception:
+            pass
     if world == 1 and not args.no_detect:
         del step, images
         model._engines = {}
