@@ -336,6 +336,11 @@ size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C);
 int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                      const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
                      int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype, void* stream);
+/* ... one launch at a time (phase 1 = the reduce pass, 2 = the apply pass, 3 = both): lets a caller that schedules other
+ * work between them (the engine forks a weight gradient behind the reduce pass, Y5M_WGRAD_FORK=2) do so */
+int y5m_bn_bwd_fused_phase(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
+                           int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype, void* stream, int phase);
 int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
                float* dbeta, int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes,

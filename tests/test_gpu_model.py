@@ -365,6 +365,21 @@ def test_config2_first_step_loss_kernel_variants_subprocess(env):
     assert r.returncode == 0, (env, r.stdout[-3000:] + r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("env", [{"Y5M_WGRAD_PC": "11"}, {"Y5M_WGRAD_PC": "59", "Y5M_WGRAD_FORK": "2"}])
+def test_bf16_train_step_backward_variants_subprocess(env):
+    """the bf16 train step against the quantisation-aware oracle (B = 16 @ 320x320: logits, loss, gradient norm) and the
+    graph-replayed bf16 step with the alternative backward paths switched in: producer / consumer weight gradients with
+    register staging (11) and with LDS-DMA staging (59) on every layer they take, and the weight gradient forked behind the
+    next BatchNorm backward's reduce launch (y5m_bn_bwd_fused_phase); child processes (knobs are read once per process)"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_VARIANT_CHILD") == "1":
+        pytest.skip("already the child")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
+                        "bf16_train_step_vs_quantisation_aware_oracle or native_train_step_graph_replay_bf16"],
+                       env=dict(os.environ, Y5M_VARIANT_CHILD="1", **env), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (env, r.stdout[-3000:] + r.stderr[-2000:])
+
+
 def test_multi_scale_plan_cache_eviction_and_graphs(monkeypatch):
     """multi_scale training alternates input sizes (reference utils/training_utils.py:11-28): with a plan cache of ONE
     entry every size change evicts the other size's plan (Engine.release: launch lists and tensors dropped, HBM back

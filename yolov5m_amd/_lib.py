@@ -147,6 +147,8 @@ _SIGS = {
                                  c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "y5m_bn_bwd_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                  c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "y5m_bn_bwd_fused_phase": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),
     "y5m_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                          c_int, c_void_p, c_size_t, c_int, c_void_p]),

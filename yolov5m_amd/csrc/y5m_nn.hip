@@ -849,27 +849,40 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
 
 // The same backward in TWO launches: the reduce pass adds its block partials into acc [y5m_bn_acc_slots()][2][C] f64
 // (zeroed by the caller; left dirty), the apply pass derives its coefficients and dgamma / dbeta from them (y5m_bnfuse.h).
+extern "C" int y5m_bn_bwd_fused_phase(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
+                                      float* dbeta, int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype,
+                                      void* stream, int phase) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    Y5M_REQUIRE(acc && scale && shift && mean && invstd, "null pointer");
+    Y5M_REQUIRE(phase >= 1 && phase <= 3, "phase: 1 = reduce, 2 = apply, 3 = both");
+    hipStream_t st = y5m_stream(stream);
+    if (phase & 1) {
+        static int rgx = -1;                   // Y5M_BNR_GX: workgroups of the reduce pass (no partial rows to pay for here)
+        if (rgx < 0) { const char* e = getenv("Y5M_BNR_GX"); rgx = e ? atoi(e) : BNR_MAX_GX; }
+        const EwGeom grr = ew_geom(M, C / 8, rgx, BNR_THREADS);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(grr.gx, (unsigned)grr.groups), dim3(BNR_THREADS), 0, st,
+                                             (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, grr.CG, grr.RP, act,
+                                             (float*)nullptr, acc);)
+        Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    }
+    if (phase & 2) {
+        const BnFusedBwd G{acc, invstd, 1.0f / (float)M, dgamma, dbeta, accumulate_param_grads};
+        const EwGeom ga = ew_geom(M, C / 8, BNF_EW_GX);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
+                                             (const T*)dz, lddz, (const T*)y, ldy, scale, shift, (const float*)nullptr,
+                                             (const float*)nullptr, mean, (T*)dy, lddy, M, C, ga.CG, ga.RP, act, G);)
+        Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    }
+    return Y5M_OK;
+}
+
 extern "C" int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
                                 float* dbeta, int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype,
                                 void* stream) {
-    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
-    Y5M_REQUIRE(acc && scale && shift && mean && invstd, "null pointer");
-    hipStream_t st = y5m_stream(stream);
-    static int rgx = -1;                       // Y5M_BNR_GX: workgroups of the reduce pass (no partial rows to pay for here)
-    if (rgx < 0) { const char* e = getenv("Y5M_BNR_GX"); rgx = e ? atoi(e) : BNR_MAX_GX; }
-    const EwGeom grr = ew_geom(M, C / 8, rgx, BNR_THREADS);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(grr.gx, (unsigned)grr.groups), dim3(BNR_THREADS), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, grr.CG, grr.RP, act,
-                                         (float*)nullptr, acc);)
-    Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    const BnFusedBwd G{acc, invstd, 1.0f / (float)M, dgamma, dbeta, accumulate_param_grads};
-    const EwGeom ga = ew_geom(M, C / 8, BNF_EW_GX);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, (const float*)nullptr,
-                                         (const float*)nullptr, mean, (T*)dy, lddy, M, C, ga.CG, ga.RP, act, G);)
-    Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
-    return Y5M_OK;
+    return y5m_bn_bwd_fused_phase(dz, lddz, y, ldy, scale, shift, mean, invstd, M, C, act, dgamma, dbeta,
+                                  accumulate_param_grads, dy, lddy, acc, dtype, stream, 3);
 }
 
 extern "C" int y5m_bn_bwd_from_partials(const float* part, int rows, int ldpart, const void* dz, int lddz, const void* y,

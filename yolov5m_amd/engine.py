@@ -36,6 +36,10 @@ def _kind(fn, kind):
     return fn
 
 
+def _as_list(op):
+    return op if isinstance(op, list) else [op]
+
+
 def _rup(x, m):
     return (x + m - 1) // m * m
 
@@ -106,6 +110,7 @@ class Engine:
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
+        self.fork_mode = int(os.environ.get("Y5M_WGRAD_FORK", "1"))   # 2: fork behind the next BatchNorm backward's reduce launch
         # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
         # so it runs ahead of the side stream instead of ping-ponging with it (each cross-stream wait costs
         # ~10-15 us of dependency latency inside a hipGraph); 0.63 GB per slot at B=64 / 640^2; with the weight gradient forked after the data gradient 3 slots measure
@@ -337,7 +342,7 @@ class Engine:
                     ops.append((lambda rg=rg, dz=dz, acc=acc: _lib.check(
                         L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), ()))
             # BN + SiLU backward -> dy (scratch), dgamma, dbeta
-            ops.append(self._bn_backward_op(lay, P, dz, scratch.data_ptr(), lay.cout))
+            ops.extend(_as_list(self._bn_backward_op(lay, P, dz, scratch.data_ptr(), lay.cout)))
             # weight gradient (packed f32, atomics into the zeroed gw buffer)
             wa = WgradArgs()
             wa.zeros = _lib.zero_page(self.dev).data_ptr()
@@ -468,6 +473,14 @@ class Engine:
                                            self._bnws_bytes, dt, st()), "y5m_bn_bwd_from_partials"), ())
         if self.fuse_b:
             accp = self.gw.data_ptr() + 4 * self._accb_base + 8 * lay.accb_off       # zeroed with gw at the start of the pass
+            if self.fork_mode == 2:
+                # the two launches as two list entries: the weight gradient of the layer above is forked between them
+                def phase(ph):
+                    return lambda: _lib.check(
+                        L.y5m_bn_bwd_fused_phase(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(),
+                                                 bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]),
+                                                 _lib.ptr(P["gb"]), 0, scratch_ptr, lddy, accp, dt, st(), ph), "y5m_bn_bwd_fused_phase")
+                return [(_kind(phase(1), "bn_reduce"), ()), (phase(2), ())]
             return (lambda: _lib.check(
                 L.y5m_bn_bwd_fused(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                                    bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0,
@@ -634,7 +647,7 @@ class Engine:
             ops.append((self._join_op(slot), ()))
             for lay, P in halves:
                 ops.extend(self._flush_lazy(lay.z))
-                ops.append(self._bn_backward_op(lay, P, lay.z.grad, scratch.data_ptr() + lay.off * esz, N2))
+                ops.extend(_as_list(self._bn_backward_op(lay, P, lay.z.grad, scratch.data_ptr() + lay.off * esz, N2)))
             wa = WgradArgs()
             wa.zeros = _lib.zero_page(self.dev).data_ptr()
             wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * gw_off
@@ -888,6 +901,16 @@ class Engine:
                         while j < len(self.bwd) and getattr(self.bwd[j][0], "kind", None) == "conv_igemm":
                             out.append(self.bwd[j])
                             j += 1
+                        if self.fork_mode == 2:
+                            # Y5M_WGRAD_FORK=2: ... and behind the NEXT BatchNorm backward's reduce launch (it starts on an
+                            # empty chip; the weight gradient then runs next to the apply launch and what follows). Never
+                            # across another weight gradient or a join (the dy ring's order is kept).
+                            k = j
+                            while k < len(self.bwd) and getattr(self.bwd[k][0], "kind", None) not in ("wgrad", "join", "bn_reduce"):
+                                k += 1
+                            if k < len(self.bwd) and getattr(self.bwd[k][0], "kind", None) == "bn_reduce":
+                                out.extend(self.bwd[j:k + 1])
+                                j = k + 1
                         out.append(op)
                         i = j
                     else:
