@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for f in glob.glob("gpurun_out/pmc/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-50:]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:70]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
     if "conv_igemm" in k or "wgrad" in k or "conv_pw" in k:
