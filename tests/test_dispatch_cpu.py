@@ -93,6 +93,7 @@ WGRAD_FORMS = {
     "3": ("wgrad_pc_kernel<2,2,3,6>", "wgrad_pc_kernel<2,2,3,3>", "wgrad_pc_kernel<2,2,3,6>"),
     "57": ("wgrad_dma_kernel<2,2,6,6,2>", "wgrad_kernel<bf16,2,2,1,3,1,3,1,1,0>", "wgrad_dma_kernel<2,2,6,6,2>"),
     "19": ("wgrad_dma_kernel<2,2,3,6,4>", "wgrad_dma_kernel<2,2,3,3,4>", "wgrad_dma_kernel<2,2,3,6,4>"),
+    "89": ("wgrad_dma_kernel<2,2,6,6,1>", "wgrad_kernel<bf16,2,2,1,3,1,3,1,1,0>", "wgrad_dma_kernel<2,2,6,6,1>"),
 }
 
 

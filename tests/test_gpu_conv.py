@@ -400,7 +400,7 @@ def test_conv_wgrad(case, dtype):
 
 # ---- wide-layer weight gradients (the 192 x 96 and 96 x 96 block tiles of wgrad_kernel, and their producer / consumer
 # forms wgrad_pc_kernel / wgrad_dma_kernel: Y5M_WGRAD_PC, bit 0 = 192 x 96 tile, bit 1 = 96 x 96 tile, bit 3 = 192 x 192 tile,
-# bits 4 / 5 = LDS-DMA staging from 4 / 2 producer waves). Ragged pixel counts (tail chunk),
+# bits 4 / 5 = LDS-DMA staging from 4 / 2 producer waves, bit 6 = from one). Ragged pixel counts (tail chunk),
 # widths that are not a multiple of the 64-pixel chunk (rows and images change inside a chunk), stride 2, channel counts
 # that leave a partial channel tile, and enough pixels for several chunks per split-K range.
 WGRAD_WIDE_CASES = [
@@ -438,15 +438,15 @@ def test_conv_wgrad_wide_layers(case):
     assert _relerr(got, w.grad) < TOL["bf16"], (case, ops.LAST_WGRAD_KERNEL, _relerr(got, w.grad))
 
 
-@pytest.mark.parametrize("form", ["pc", "dma4", "dma2"])
+@pytest.mark.parametrize("form", ["pc", "dma4", "dma2", "dma1"])
 def test_wgrad_other_form_subprocess(form):
     """the weight-gradient forms that are NOT the default of this build (producer / consumer workgroups with register
-    staging, with LDS-DMA staging from four / two producer waves; or the 4-wave kernel when one of those is the default) on
+    staging, with LDS-DMA staging from four / two / one producer waves; or the 4-wave kernel when one of those is the default) on
     the same cases, in a child process (the knob is read once per process)"""
     import os, subprocess, sys
     if os.environ.get("Y5M_WGRAD_TEST_CHILD") == "1":
         pytest.skip("already the child")
-    other = {"pc": "11", "dma4": "27", "dma2": "59"}[form]
+    other = {"pc": "11", "dma4": "27", "dma2": "59", "dma1": "89"}[form]
     if _wgrad_pc_bits() == int(other):
         other = "0"
     env = dict(os.environ, Y5M_WGRAD_PC=other, Y5M_WGRAD_TEST_CHILD="1")

@@ -712,10 +712,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void wgrad_dma_kernel(const WgradPa
     static_assert(KCH == 64, "two 32-pixel groups per chunk");
     constexpr int BUF = C::YB + C::XB, NB = 3;
     constexpr int YS = C::TN / 16, XS = C::TC / 16;       // sub-tiles per 32-pixel group
-    constexpr int SH = NPW / 2;                           // producer waves per pixel group
-    static_assert(NPW == 2 || NPW == 4, "producer waves");
+    constexpr int NG = NPW == 1 ? 2 : 1;                  // pixel groups per producer wave (one wave: both)
+    constexpr int SH = NPW == 1 ? 1 : NPW / 2;            // producer waves per pixel group
+    static_assert(NPW == 1 || NPW == 2 || NPW == 4, "producer waves");
     static_assert(YS % SH == 0 && XS % SH == 0, "sub-tiles split evenly");
-    constexpr int NDY = YS / SH, NDX = XS / SH, NDW = NDY + NDX;      // DMA instructions per producer wave and chunk
+    constexpr int NDY = YS / SH, NDX = XS / SH, NDW = NG * (NDY + NDX);      // DMA instructions per producer wave and chunk
+    static_assert(NDW <= 63, "counted vmcnt");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -744,44 +746,49 @@ __global__ __launch_bounds__(256 + 64 * NPW) void wgrad_dma_kernel(const WgradPa
             const_cast<void*>(P.dy), 0, (unsigned)((size_t)P.M * P.lddy * sizeof(T)), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(P.x), 0, (unsigned)((size_t)P.B * P.Hin * P.Win * P.ldx * sizeof(T)), 0x00020000);
-        const int pw = wid - 4, g = pw % 2, h = pw / 2;
+        const int pw = wid - 4, g0 = NPW == 1 ? 0 : pw % 2, h = NPW == 1 ? 0 : pw / 2;
         const int px = lane >> 1, half = lane & 1;
         const int ta = tap0 / P.tw, tb = tap0 - ta * P.tw;
         const int xdh = P.dh0 + ta * P.dhs, xdw = P.dw0 + tb * P.dws;
         const unsigned ldxb = (unsigned)(P.ldx * sizeof(T)), ldyb = (unsigned)(P.lddy * sizeof(T));
-        // this lane's pixel of the chunk the state points at: m = chunk * 64 + g * 32 + px
-        int gx, gy, gb;
-        unsigned yoff;                                        // dY: row m, this wave's first sub-tile, this lane's half
-        {
+        // this lane's pixel of the chunk the state points at, per pixel group of this wave: m = chunk * 64 + g * 32 + px
+        int gx[NG], gy[NG], gb[NG];
+        unsigned yoff[NG];                                    // dY: row m, this wave's first sub-tile, this lane's half
+        unsigned ydst[NG], xdst[NG];                          // LDS address of the wave's first dY / X sub-tile inside a buffer
+        const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const int g = g0 + q;
             const int m = ch_lo * KCH + g * 32 + px;
-            yoff = (unsigned)m * ldyb + (unsigned)((n0 + h * NDY * 16 + half * 8) * sizeof(T));
-            const float rcpW = 1.0f / (float)P.Wg, rcpH = 1.0f / (float)P.Hg;
+            yoff[q] = (unsigned)m * ldyb + (unsigned)((n0 + h * NDY * 16 + half * 8) * sizeof(T));
             int t;
-            fast_divmod(m, P.Wg, rcpW, t, gx);
-            fast_divmod(t, P.Hg, rcpH, gb, gy);
+            fast_divmod(m, P.Wg, rcpW, t, gx[q]);
+            fast_divmod(t, P.Hg, rcpH, gb[q], gy[q]);
+            ydst[q] = lds0 + (unsigned)((g * YS + h * NDY) * WG_SUB);
+            xdst[q] = lds0 + (unsigned)(C::YB + (g * XS + h * NDX) * WG_SUB);
         }
         const unsigned xch = (unsigned)((c0 + h * NDX * 16 + half * 8) * sizeof(T));
         const int stepx = KCH % P.Wg, stepy = (KCH / P.Wg) % P.Hg, stepb = KCH / (P.Wg * P.Hg);
-        // LDS address of this wave's first dY / X sub-tile inside a buffer
-        const unsigned ydst = lds0 + (unsigned)((g * YS + h * NDY) * WG_SUB);
-        const unsigned xdst = lds0 + (unsigned)(C::YB + (g * XS + h * NDX) * WG_SUB);
         auto issue = [&](unsigned boff) __attribute__((always_inline)) {     // the chunk the state points at -> buffer at boff; advance
-            const int iy = gy * P.sy + xdh, ix = gx * P.sx + xdw;
-            const bool in = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            const unsigned pix = __umul24((unsigned)(gb * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
-            const unsigned xoff = in ? __umul24(pix, ldxb) + xch : OOB;
 #pragma unroll
-            for (int i = 0; i < NDY; ++i) wg_dma16(rs_y, yoff + (unsigned)(i * 32), ydst + boff + (unsigned)(i * WG_SUB));
+            for (int q = 0; q < NG; ++q) {
+                const int iy = gy[q] * P.sy + xdh, ix = gx[q] * P.sx + xdw;
+                const bool in = (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                const unsigned pix = __umul24((unsigned)(gb[q] * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
+                const unsigned xoff = in ? __umul24(pix, ldxb) + xch : OOB;
 #pragma unroll
-            for (int i = 0; i < NDX; ++i) wg_dma16(rs_x, xoff + (unsigned)(i * 32), xdst + boff + (unsigned)(i * WG_SUB));
-            yoff += (unsigned)KCH * ldyb;
-            gx += stepx;
-            const int c1 = gx >= P.Wg ? 1 : 0;
-            gx -= c1 ? P.Wg : 0;
-            gy += stepy + c1;
-            const int c2 = gy >= P.Hg ? 1 : 0;
-            gy -= c2 ? P.Hg : 0;
-            gb += stepb + c2;
+                for (int i = 0; i < NDY; ++i) wg_dma16(rs_y, yoff[q] + (unsigned)(i * 32), ydst[q] + boff + (unsigned)(i * WG_SUB));
+#pragma unroll
+                for (int i = 0; i < NDX; ++i) wg_dma16(rs_x, xoff + (unsigned)(i * 32), xdst[q] + boff + (unsigned)(i * WG_SUB));
+                yoff[q] += (unsigned)KCH * ldyb;
+                gx[q] += stepx;
+                const int c1 = gx[q] >= P.Wg ? 1 : 0;
+                gx[q] -= c1 ? P.Wg : 0;
+                gy[q] += stepy + c1;
+                const int c2 = gy[q] >= P.Hg ? 1 : 0;
+                gy[q] -= c2 ? P.Hg : 0;
+                gb[q] += stepb + c2;
+            }
         };
         // (chunks behind the block's range are issued as well -- the loop has no branch; behind the tensor they read as zeros)
         issue(0u);
@@ -978,7 +985,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         attr = true;
     }
     if constexpr (PC >= 2 && sizeof(T) == 2 && TPB == 1 && WK == 1 && KX == 1) {
-        constexpr int NPW = PC == 2 ? 4 : 2;
+        constexpr int NPW = PC == 2 ? 4 : PC == 3 ? 2 : 1;
         auto dk = wgrad_dma_kernel<WN, WC, CFR, NFR, NPW>;
         static bool dattr = false;
         if (!dattr) {
@@ -1055,7 +1062,7 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     }
     if constexpr (sizeof(T) == 2) {
         // Y5M_WGRAD_PC: producer / consumer form (bit 0: the 192 x 96 tile, bit 1: the 96 x 96 tile; bit 2: also pointwise layers;
-        // bit 3: a 192 x 192 tile where both channel counts allow it; bits 4 / 5: wgrad_dma_kernel with 4 / 2 producer waves)
+        // bit 3: a 192 x 192 tile where both channel counts allow it; bits 4 / 5: wgrad_dma_kernel with 4 / 2 producer waves, bit 6 (with 4 or 5): one)
         static int pc = -1;
         if (pc < 0) { const char* e = getenv("Y5M_WGRAD_PC"); pc = e ? atoi(e) : 0; }
         static int pcsel = -1;              // Y5M_WGRAD_PC_SEL: 0 = every eligible layer, 1 = stride-2 layers only, 2 = C >= 384 only, 3 = either
@@ -1064,6 +1071,8 @@ static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
         if (sel && (pc & 48) && P.slices_cap <= 0 && (taps > 1 || (pc & 4)) && P.C % 16 == 0 && P.N % 16 == 0) {
             // bits 4 / 5: LDS-DMA producers (4 / 2 producer waves); full channel tiles only
             const bool two = (pc & 32) != 0;
+            if ((pc & 64) && (pc & 8) && P.N % 192 == 0 && P.C % 192 == 0) return launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 4>(P, st);   // bit 6: ONE producer wave
+            if ((pc & 64) && (pc & 1) && big && P.N % 192 == 0 && P.C % 96 == 0) return launch_wgrad<T, 2, 2, 1, 3, 1, 6, 1, false, 4>(P, st);
             if ((pc & 8) && P.N % 192 == 0 && P.C % 192 == 0)
                 return two ? launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 3>(P, st) : launch_wgrad<T, 2, 2, 1, 6, 1, 6, 1, false, 2>(P, st);
             if ((pc & 1) && big && P.N % 192 == 0 && P.C % 96 == 0)
