@@ -239,6 +239,33 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5):
                         f"(obj ~ N(-5,2^2)), max_detections 300 (BASELINE.json configs[4])", "unit": "boxes/s", **out}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run in front: start the N ranks ourselves (one process per GPU,
+    rendezvous on 127.0.0.1 and a free port) by re-executing this command line under torch.distributed.run. Returns the
+    launcher's exit code. Refuses loudly when fewer than N devices are visible (unless Y5M_DIST_BACKEND=gloo, which folds
+    the ranks onto the visible devices: the 1-GPU box's way to run the whole multi-process flow)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("Y5M_DIST_BACKEND") != "gloo":
+        sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to report a {n}-GPU number\n")
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL / cross-process device memory on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,7 +278,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-detect", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the backward pass instead of the bucketed, overlapped exchange")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch.distributed as dist
     from yolov5m_amd import _lib, config, parallel
@@ -261,7 +291,12 @@ def main():
     from yolov5m_amd.utils.synth import synth_images, synth_labels
 
     rank, local, world = parallel.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
+    backend = dist.get_backend() if world > 1 else None
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s)")
+    local = torch.cuda.current_device() if world > 1 else local      # (gloo on a smaller box: ranks folded onto the devices)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     _lib.check(_lib.lib().y5m_device_ok(), "y5m_device_ok")
@@ -275,8 +310,9 @@ def main():
     model.flatten_parameters()
     parallel.broadcast_parameters(model)
     loss_fn = ComputeLoss(model)
-    hook = parallel.GradAllReduce(world) if world > 1 else None
-    step = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook)
+    hook = parallel.GradAllReduce(world, timing=True) if world > 1 else None
+    step = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook,
+                           overlap=not args.no_overlap)
 
     # inputs resident in HBM before timing: the batch is written once into the step's static input buffer (what a
     # device-side loader / y5m_preprocess_u8 does), so step() makes no further copy of the images
@@ -306,6 +342,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     final_loss = float(lo[0])
+    # the exchange of the LAST timed step on every rank: per-bucket milliseconds (gradients final -> reduced) and the time
+    # the compute stream waited for it before the optimizer; rank 0 reports the maximum over ranks
+    xstats = hook.stats() if hook is not None else None
+    if world > 1:
+        nb = len(xstats["buckets"]) if xstats else 0
+        v = torch.tensor(([b["ms"] for b in xstats["buckets"]] + [xstats["allreduce_exposed_ms"]]) if xstats else [0.0],
+                         dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        if xstats:
+            for b, ms_ in zip(xstats["buckets"], v[:nb].tolist()):
+                b["ms"] = round(ms_, 3)
+            xstats["allreduce_exposed_ms"] = round(float(v[nb]), 3)
 
     if rank != 0:
         if world > 1:
@@ -315,7 +363,8 @@ def main():
     value = world * B * args.steps / dt
     out = {
         "metric": "images/sec (train step, 640x640)", "value": round(value, 2), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "dist_backend": backend,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"YOLOv5m full train step (fwd + ComputeLoss + bwd + clip + Adam), batch {B}/GPU @ "
                                f"{S}x{S}, random-init weights, 8 boxes/image (BASELINE.json configs[2]"
@@ -323,12 +372,26 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph, **first_loss_check(first_loss, B, S, rank),
                    "final_loss": round(final_loss, 4)},
     }
+    if world > 1:
+        out["exchange"] = {"what": "SUM all-reduce of the flat f32 gradient buffer (84.8 MB), "
+                                   + ("one message after the backward pass" if args.no_overlap else
+                                      "bucketed in backward order and overlapped with the backward pass (one captured "
+                                      "graph per segment; buckets issued from a communication stream)"),
+                           "last_step_max_over_ranks": xstats}
     if not args.no_roofline:
         fams = {}
         cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
         esz = 2 if args.dtype == "bf16" else 4
-        kernels = {}
+        kernels, insitu = {}, {}
         for _ in range(2):
+            # the step's OWN schedule (weight gradients on the forked stream next to the main stream's kernels), every
+            # launch timed by HIP events on the stream it runs on: what a launch costs inside the step
+            _f, _c, kern = step.profile_step(images, targets, detail="kernels", overlapped=True)
+            for name, ms_, fl in kern:
+                k = insitu.setdefault(name, [0.0, 0.0, 0])
+                k[0] += ms_; k[1] += fl; k[2] += 1
+        for _ in range(2):
+            # the same launches with the forked stream serialised: per-family times that add up
             fam, convs, kern = step.profile_step(images, targets, detail="kernels")
             for name, ms_, fl in kern:
                 k = kernels.setdefault(name, [0.0, 0.0, 0])
@@ -351,22 +414,29 @@ def main():
         conv_n //= 2
         achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
         wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
-        # headline = the ONE kernel instantiation with the largest share of the step (by summed launch time, HIP events on
-        # the launching stream, side stream serialised); the conv family and the per-kernel table sit beside it
-        ranked = sorted(kernels.items(), key=lambda kv: -kv[1][0])
+        # headline = the ONE kernel instantiation with the largest share of the step, by summed launch time INSIDE the
+        # step's own overlapped schedule (HIP events on the launching stream); `frac` is that in-situ figure, the
+        # serialised one (forked stream run inline) sits beside it; the conv family and the per-kernel table follow
+        ranked = sorted(insitu.items(), key=lambda kv: -kv[1][0])
         dom_name, (dom_ms, dom_fl, dom_n) = ranked[0]
         dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12
+        ser_ms, ser_fl, ser_n = kernels.get(dom_name, (dom_ms, dom_fl, dom_n))
+        ser_tf = ser_fl / (ser_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dom_name)
         out["roofline"] = {
             "bound": "mfma", "kernel": dom_name,
             "achieved": round(dom_tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dom_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "timing": "HIP events around every launch on its own stream, inside the step's overlapped schedule (eager pass)",
             "launches_per_step": dom_n // 2, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
             "algorithmic_gflop_per_launch": round(dom_fl / max(dom_n, 1) / 1e9, 2),
             "share_of_step_ms": round(dom_ms / 2, 3),
+            "achieved_serialised": round(ser_tf, 2), "frac_serialised": round(ser_tf / PEAK_BF16_TFLOPS, 4),
+            "avg_launch_us_serialised": round(ser_ms * 1e3 / max(ser_n, 1), 2),
             "by_kernel": [{"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
                            "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
-                           "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)} for n_, v in ranked[:8]],
+                           "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                           "ms_per_step_serialised": round(kernels.get(n_, v)[0] / 2, 3)} for n_, v in ranked[:8]],
             "conv_family": {"what": "forward conv + data gradient, all y5m_conv launches of one step",
                             "achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                             "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),

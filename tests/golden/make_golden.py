@@ -337,6 +337,63 @@ def g9_nms_aladdin():
     save("g9_nms_aladdin", **out)
 
 
+def g14_nms_crosspin():
+    """Cross-pin of the torchvision-0.12 NMS restatement (absent from /root/reference and from this image) against NMS
+    arithmetic the reference DOES hold: its own `non_max_suppression_aladdin` (utils/bboxes_utils.py:129-173). On tie-free,
+    single-class inputs with max_detections >= N and every pairwise IoU at least 1e-4 away from the threshold, the two
+    define the same kept set in the same order: aladdin keeps a box iff IoU(+1e-7 in the union) < thr against every kept
+    box of its class, torchvision suppresses iff IoU > thr -- the 1e-7 epsilon and the </> boundary cannot matter at that
+    margin. Boxes are midpoint rows [cls, score, x, y, w, h] whose corner conversion is EXACT in float32 (x1, y1 multiples
+    of 1/4, w, h multiples of 1/2), so the reference's wrapper order x1=x-w/2; y1=y-h/2; y2=h+y1; x2=w+x1 (:190-193) and
+    the corners handed to aladdin are the same float32 numbers. Stored: the midpoint rows, the corners, the kept indices."""
+    from utils import bboxes_utils as RB
+    out, names = {}, []
+    for N, iou_thr, seed in ((64, 0.45, 1), (65, 0.6, 2), (1000, 0.45, 3), (1000, 0.6, 4), (5000, 0.45, 5), (5000, 0.6, 6)):
+        rng = np.random.default_rng(1400 + seed)
+        span = {64: 200, 65: 200, 1000: 500, 5000: 900}[N]
+        while True:
+            x1 = np.floor(rng.uniform(0, span, N) * 4) / 4
+            y1 = np.floor(rng.uniform(0, span, N) * 4) / 4
+            w = np.floor(rng.uniform(30, 110, N) * 2) / 2
+            h = np.floor(rng.uniform(30, 110, N) * 2) / 2
+            c = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.float64)
+            # every pairwise IoU (float64) clear of the threshold by 1e-4; chunked to bound memory
+            ok = True
+            area = (c[:, 2] - c[:, 0]) * (c[:, 3] - c[:, 1])
+            for i0 in range(0, N, 500):
+                a = c[i0:i0 + 500, None, :]
+                iw = np.clip(np.minimum(a[..., 2], c[None, :, 2]) - np.maximum(a[..., 0], c[None, :, 0]), 0, None)
+                ih = np.clip(np.minimum(a[..., 3], c[None, :, 3]) - np.maximum(a[..., 1], c[None, :, 1]), 0, None)
+                inter = iw * ih
+                iou = inter / (area[i0:i0 + 500, None] + area[None, :] - inter)
+                if (np.abs(iou - iou_thr) < 1e-4).any():
+                    ok = False
+                    break
+            if ok:
+                break
+        score = (rng.permutation(N).astype(np.float32) + 1.0) / np.float32(N + 1)      # tie-free, all > the 1e-4 score threshold
+        assert len(np.unique(score)) == N and score.min() > 1e-4
+        mid = np.zeros((N, 6), np.float32)
+        mid[:, 1] = score
+        mid[:, 2], mid[:, 3], mid[:, 4], mid[:, 5] = x1 + w / 2, y1 + h / 2, w, h
+        xa = mid[:, 2] - mid[:, 4] / 2; ya = mid[:, 3] - mid[:, 5] / 2          # the wrapper's float32 arithmetic, in its order
+        yb = mid[:, 5] + ya; xb = mid[:, 4] + xa
+        corners = np.stack([xa, ya, xb, yb], 1).astype(np.float32)
+        assert np.array_equal(corners.astype(np.float64), c), "corner conversion must be exact"
+        lst = [[0.0, float(s)] + [float(v) for v in cc] for s, cc in zip(score, corners)]
+        kept = RB.non_max_suppression_aladdin(lst, iou_thr, 1e-4, box_format="corners", max_detections=N)
+        assert len(kept) <= 1000            # (the native kernel's max_detections bound is 1024)
+        pos = {id(r): i for i, r in enumerate(lst)}
+        keep = np.array([pos[id(r)] for r in kept], dtype=np.int64)
+        name = f"n{N}_i{iou_thr}"
+        out[f"{name}/mid"], out[f"{name}/corners"], out[f"{name}/keep"] = mid, corners, keep
+        out[f"{name}/par"] = np.array([1e-4, iou_thr])
+        names.append(name)
+        print(name, "kept", len(keep))
+    out["names"] = np.array(names)
+    save("g14_nms_crosspin", **out)
+
+
 def g10_config0(model):
     """BASELINE.json configs[0] (the reference's own CPU-runnable case, ultralytics_files/my_loss_vs_ultra_loss.py
     :26-33): torch.manual_seed(355); images = rand(4,3,640,640); 12 labels [img, cls, x, y, w, h] with
@@ -556,6 +613,51 @@ def g13_fp64_and_full_gradients(model):
 
 
 # ------------------------------------------------------------------------------------------------
+def g15_full_size_backward(model):
+    """configs[2] at FULL size: the real reference's f32 forward + ComputeLoss + backward at B = 64 @ 640x640 on bench.py's
+    own inputs and initial weights (torch.manual_seed(0) default init, synth images / labels of rank 0). Stored: the loss,
+    the L2 norm of every one of the 243 parameter gradients, the total norm, and 256 sampled elements of 32 tensors spread
+    over the network. Memory: autograd would hold ~40 GB of saved activations at this size, so every top-level block of
+    the backbone and neck is wrapped in torch.utils.checkpoint (the block's own forward is re-run during backward: the
+    gradients are those of the un-wrapped model up to f32 re-association; BatchNorm batch statistics are recomputed from
+    the same inputs). The reference code itself is untouched."""
+    from torch.utils.checkpoint import checkpoint
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd import config as C
+    torch.manual_seed(0)
+    mine = YOLOV5m(first_out=C.FIRST_OUT, nc=80, anchors=C.ANCHORS, ch=(C.FIRST_OUT * 4, C.FIRST_OUT * 8, C.FIRST_OUT * 16))
+    model.load_state_dict(mine.state_dict(), strict=True)
+    model.train(True)
+    model.zero_grad()
+    for seq in (model.backbone, model.neck):
+        for blk in seq:
+            blk.forward = (lambda x, f=blk.forward: checkpoint(f, x, use_reentrant=False))
+    B, S = 64, 640
+    x = synth_images(B, S, S, seed="img/rank0").requires_grad_(True)     # (a checkpointed block needs a grad-requiring input)
+    t = synth_labels(B, 8, seed="lab/rank0")
+    lf = R.ComputeLoss(model)
+    o = model(x)
+    loss = lf(o, t, None)
+    loss.backward()
+    named = list(model.named_parameters())
+    out = {"loss": np.array(float(loss)), "names": np.array([k for k, _ in named])}
+    norms = np.array([float(p.grad.double().norm()) for _, p in named])
+    out["norm"] = norms
+    out["total_norm"] = np.array(float(np.sqrt((norms ** 2).sum())))
+    pick = sorted(set(np.linspace(0, len(named) - 1, 32).round().astype(int).tolist()))
+    out["sampled"] = np.array(pick, dtype=np.int64)
+    samples = []
+    for i in pick:
+        g = named[i][1].grad.reshape(-1).numpy()
+        v = np.zeros(256, np.float32)
+        idx = _sample_idx(g.size)
+        v[:idx.size] = g[idx]
+        samples.append(v)
+    out["sample"] = np.array(samples)
+    print("g15: loss", float(loss), "total grad norm", float(out["total_norm"]))
+    save("g15_full_size_backward", **out)
+
+
 def g12_yolo_build_targets(model):
     """YOLO_LOSS.build_targets of the REAL reference at batch scale: a fresh loss object, two calls of 16 images x 8
     boxes at 320x320 (cell grids 40 / 20 / 10). 256 boxes in a row walk the loss object's anchors through the whole
@@ -593,7 +695,7 @@ def g12_yolo_build_targets(model):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -609,3 +711,5 @@ if __name__ == "__main__":
     if "g11" in which: g11_eval_path(model)
     if "g12" in which: g12_yolo_build_targets(model)
     if "g13" in which: g13_fp64_and_full_gradients(model)
+    if "g14" in which: g14_nms_crosspin()
+    if "g15" in which: g15_full_size_backward(model)        # (not in the default list: ~10 min and ~25 GB of host memory)

@@ -127,6 +127,22 @@ def test_nms_api_shapes(golden):
     assert cat.shape == (len(lst[0]) + len(lst[1]), 6)
 
 
+def test_nms_kernel_pinned_by_reference_aladdin(golden):
+    """nms_kernel against the kept lists the REAL reference's `non_max_suppression_aladdin` produced (g14: tie-free,
+    single class, IoUs clear of the threshold -- where it and torchvision.ops.nms define the same set; see
+    tests/test_oracle_golden.py::test_nms_restatement_pinned_by_reference_aladdin): index sets bit-exact, rows = the
+    reference wrapper's corner conversion of the kept boxes."""
+    from yolov5m_amd.utils.bboxes_utils import nms_batched
+    g = golden("g14_nms_crosspin")
+    for name in g["names"].tolist():
+        thr, iou = g[f"{name}/par"].tolist()
+        mid, corners, keep = g[f"{name}/mid"], g[f"{name}/corners"], g[f"{name}/keep"]
+        rows, idx, cnt = nms_batched(torch.from_numpy(mid[None]).to(DEV), float(iou), float(thr), 1024)
+        k = int(cnt[0])
+        assert k == len(keep) and idx[0, :k].cpu().tolist() == keep.tolist(), name
+        assert np.array_equal(rows[0, :k, 2:].cpu().numpy(), corners[keep]), name
+
+
 @pytest.mark.parametrize("N,thr,iou", [(25200, 0.01, 0.6), (25200, 0.25, 0.45), (100800, 0.01, 0.6)])
 def test_nms_large_random(N, thr, iou):
     """> NMS_CAP candidates: exercises the radix-select rounds."""

@@ -162,10 +162,29 @@ def test_g6_nms_rows_bit_exact(golden):
                 assert np.array_equal(bx[b][idx][:, :2], rows[:, :2])
 
 
-def test_nms_vs_reference_pure_python_aladdin():
-    """Semantic cross-check of the torchvision restatement against the reference's OWN greedy NMS
-    (utils/bboxes_utils.py:129-173), stored as a golden by make_golden? -- no: run on tie-free
-    single-class inputs where the two definitions coincide, using an independent numpy greedy."""
+def test_nms_restatement_pinned_by_reference_aladdin(golden):
+    """A12's inner kernel, pinned by reference-held code: torchvision.ops.nms 0.12 is absent from /root/reference and from
+    this image, but the reference's OWN greedy NMS (`non_max_suppression_aladdin`, utils/bboxes_utils.py:129-173) defines
+    the same kept set in the same order on tie-free single-class inputs with max_detections >= N and every pairwise IoU
+    >= 1e-4 away from the threshold (g14, produced by the REAL reference function in make_golden.py). The C restatement
+    of torchvision's algorithm, the restated wrapper (midpoint rows -> corners in the reference's order) and the C
+    restatement of aladdin must all keep exactly that list."""
+    g = golden("g14_nms_crosspin")
+    for name in g["names"].tolist():
+        thr, iou = g[f"{name}/par"].tolist()
+        mid, corners, keep = g[f"{name}/mid"], g[f"{name}/corners"], g[f"{name}/keep"]
+        N = mid.shape[0]
+        assert cnative.nms_tv012(corners, mid[:, 1], iou).tolist() == keep.tolist(), name
+        rows, idx = loss_ref.non_max_suppression(mid[None], float(iou), float(thr), N)[0]
+        assert idx.tolist() == keep.tolist(), name
+        assert np.array_equal(rows[:, 2:], corners[keep]) and np.array_equal(rows[:, 1], mid[keep, 1])
+        al = np.concatenate([mid[:, :2], corners], 1)
+        assert cnative.nms_aladdin(al, iou, thr, "corners", N).tolist() == keep.tolist(), name
+
+
+def test_nms_restatement_vs_independent_numpy_greedy():
+    """the torchvision restatement against an independent numpy greedy written here (same published algorithm: areas,
+    stable descending order, max(0,.) clamps, `ovr > double(thr)`) on tie-free single-class boxes"""
     rng = np.random.default_rng(9)
     N = 400
     xy = rng.uniform(0, 300, (N, 2)).astype(np.float32)

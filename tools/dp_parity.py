@@ -44,7 +44,7 @@ for r in range(world):
     m._engines.clear()
 m = model()
 parallel.broadcast_parameters(m)
-hook = parallel.GradAllReduce(world)
+hook = parallel.GradAllReduce(world, timing=True)
 step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=True, grad_hook=hook, overlap=True)
 x, t = batch(rank)
 lo = step.step(x, t)
@@ -53,6 +53,7 @@ cuts = step.model._engines[next(iter(step.model._engines))]._cuts
 assert len(cuts) >= 1, cuts
 err = float((m.flat_grads - ref).abs().max() / ref.abs().max())
 assert err < 1e-4, ("summed gradient", err)
+g_overlapped = m.flat_grads.clone()
 
 # ---- 2. identical parameters after captured steps ------------------------------------------------------------------
 for _ in range(3):
@@ -65,19 +66,27 @@ dist.all_gather(gathered, mine)
 for g in gathered:
     assert torch.equal(g, gathered[0]), "parameters differ across ranks"
 assert bool(torch.isfinite(mine).all()) and float(lo[0]) == float(lo[0])
+st_ = hook.stats()
+assert st_ is not None and len(st_["buckets"]) == len(cuts) + 1 and st_["allreduce_exposed_ms"] >= 0.0, st_
 
 # ---- 3. un-overlapped exchange, same schedule -----------------------------------------------------------------------
 m2 = model()
 parallel.broadcast_parameters(m2)
 step2 = NativeTrainStep(m2, ComputeLoss(m2), nt_max=64, use_graph=True, grad_hook=parallel.GradAllReduce(world), overlap=False)
-for _ in range(4):
+step2.step(x, t)
+torch.cuda.synchronize()
+# both schedules sum the same per-rank gradients of the same parameters: equal up to the order of the f32 atomic adds inside
+# the weight-gradient kernels (a bucket exchanged before its gradients were final, a wrong cut or a missed join would be O(1))
+gerr = float((m2.flat_grads - g_overlapped).abs().max() / g_overlapped.abs().max())
+assert gerr < 2e-5, ("overlapped vs plain exchanged gradient", gerr)
+for _ in range(3):
     step2.step(x, t)
 torch.cuda.synchronize()
 p0 = torch.cat([p.detach().reshape(-1) for p in model().parameters()])
 d1, d2 = (mine - p0).cpu().numpy(), (m2.flat_params - p0).cpu().numpy()
 rel = np.linalg.norm(d1 - d2) / np.linalg.norm(d2)
-assert rel < 0.1, ("overlapped vs plain exchange", rel)
+assert rel < 2e-2, ("overlapped vs plain exchange", rel)     # (four Adam steps: sign-like updates amplify 1e-6 gradient noise)
 dist.barrier()
 if rank == 0:
-    print(f"dp parity ok: world {world}, cuts {cuts}, grad err {err:.2e}, overlap-vs-plain update diff {rel:.2e}")
+    print(f"dp parity ok: world {world}, cuts {cuts}, grad err {err:.2e}, overlap-vs-plain gradient diff {gerr:.2e}, update diff {rel:.2e}")
 dist.destroy_process_group()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/y5m.h"
 
 extern "C" void y5m_set_error(const char* fmt, ...);
@@ -35,6 +36,26 @@ extern thread_local char y5m_name_buf[192];
             return RET;                                                              \
         }                                                                            \
     } while (0)
+
+// Workgroups a PERSISTENT launch (one workgroup per CU: conv_halo_kernel, conv_gemm8_kernel) may use: the device's CU count,
+// capped by Y5M_PERSIST_CUS. The cap exists for data-parallel runs: a collective's kernels hold some CUs for as long as
+// a bucket is on the wire, and a persistent workgroup whose CU is taken only starts when that kernel ends -- with a static
+// tile assignment the whole launch then waits for it. Read once per process.
+static inline int y5m_persistent_cus() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0, n = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+        const char* e = getenv("Y5M_PERSIST_CUS");
+        const int cap = e ? atoi(e) : 0;
+        cus = (cap > 0 && cap < n) ? cap : n;
+    }
+    return cus;
+}
+
+int y5m_fill32(void* p, uint32_t v, size_t n_words, hipStream_t st);      // y5m_core.hip: 32-bit fill as a kernel launch
 
 static inline hipStream_t y5m_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t y5m_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

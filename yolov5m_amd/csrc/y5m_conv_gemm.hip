@@ -383,12 +383,7 @@ static int launch_gemm8(const ConvParams& P, const GemmArgs& G, hipStream_t st) 
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (g_gemm8_cus <= 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_gemm8_cus = prop.multiProcessorCount;
-        if (g_gemm8_cus <= 0) g_gemm8_cus = 256;
-    }
+    g_gemm8_cus = y5m_persistent_cus();
     // Y5M_CONV_GEMM8_NP=1 (experiment): data-gradient launches with ONE work item per workgroup (grid = items), so that the
     // workgroups are short-lived and interleave with the forked weight gradient's blocks
     static int np = -1;

@@ -601,12 +601,7 @@ static int launch_halo(const ConvParams& P, const HaloArgs& G, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (g_halo_cus <= 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_halo_cus = prop.multiProcessorCount;
-        if (g_halo_cus <= 0) g_halo_cus = 256;
-    }
+    g_halo_cus = y5m_persistent_cus();
     const int grid = G.total < g_halo_cus ? G.total : g_halo_cus;
     Y5M_NAME_ONLY(Y5M_OK, "conv_halo_kernel<%d,%d>", NF, EPI);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(HL_THREADS), lds, st, P, G);

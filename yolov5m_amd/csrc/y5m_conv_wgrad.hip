@@ -1,4 +1,4 @@
-// Weight-gradient kernel for gfx950:  dW[n][tap][c] += sum_m dY[m][n] * X[pix(m,tap)][c]
+// Weight-gradient kernels for gfx950:  dW[n][tap][c] += sum_m dY[m][n] * X[pix(m,tap)][c]
 //
 // GEMM with K = pixels. Both operands are pixel-major in HBM (NHWC), i.e. K is the STRIDED axis, so
 // the tiles are staged [pixel][channel] in LDS exactly as they are read (coalesced 16-byte chunks along
@@ -6,35 +6,24 @@
 //   bf16: ds_read_b64_tr_b16 on [32 pixel][16 channel] sub-tiles (1 KiB each, the conflict-free
 //         layout of the CDNA4 guide) -> 4 pixels of one channel per lane per read, 2 reads per operand;
 //   f32 : plain ds_read_b32, lane (channel = lane&15, pixel = lane>>4) is exactly the 16x16x4 operand.
-// Block tile (WN*16*NFR)(n) x (WC*16*CFR)(c), wave tile (16*NFR) x (16*CFR); the 4 waves are arranged WN x WC x WK: for the small-channel
-// layers (N or C <= 48, stem C = 16) the spare waves split the pixels of each chunk (WK) instead of
-// multiplying zero padding. One pixel range (split-K) per block; f32 partial tiles are combined with
+// wgrad_kernel: block tile (WN*16*NFR)(n) x (WC*16*CFR)(c), wave tile (16*NFR) x (16*CFR); the 4 waves are arranged
+// WN x WC x WK: for the small-channel layers (N or C <= 48, stem C = 16) the spare waves split the pixels of each chunk
+// (WK) instead of multiplying zero padding. One pixel range (split-K) per block; f32 partial tiles are combined with
 // atomicAdd into the packed f32 gradient (coalesced along c).
 // Taps: normally ONE tap per block (the 9 tap blocks of a pixel range run on one XCD and share dY through
-// its L2). For the small-C layers (stem C=16, the 48-channel stages) a block covers TPB taps at once: the X
-// tile is [pixel][TPB x CBLK "virtual channels"] (an im2col slice built by the loader, every 16-byte chunk
-// with its own tap offset and bounds test), so dY is read once per TPB taps and a wave gets 3 x 9 MFMAs per
-// 32-pixel step instead of 3 x 1 (stem) or 3 x 3.
-// Tried and removed (round 2): a "row-of-taps" variant for the 3x3 layers -- one 96 x 96 block computes the three
-// horizontal taps from ONE staged dY chunk and ONE X chunk (+ 2 halo rows) in a zero-padded raster, 108 accumulator
-// registers per wave, 2.2x fewer staged bytes per MFMA and dY / X leaving L2 three instead of nine times. Bit-for-bit
-// correct, but 545-560 TFLOP/s isolated against 586 for this kernel on 192 -> 192 @ 40x40 (B = 64), and 28.37 vs 27.93
-// ms/step inside the train step: with three 4-wave blocks per CU it spent 49 % of its wave cycles in s_waitcnt (PMC
-// SQ_WAIT_ANY), i.e. it is bound by the latency of its one-chunk-deep operand prefetch, not by the LDS traffic it saves.
-// Round 2, this kernel alone on a CU (one 4-wave block per CU is what the train step gives it next to the BatchNorm
-// backward): 23 % of the bf16 MFMA peak, a chunk period of ~2470 cycles for 576 cycles of MFMA. Tried, each through an
-// env knob, on 192 -> 192 @ 40x40 (B=64): 8 waves as 2 K-waves of 96 x 96 (Y5M_WGRAD_BIG=4: 585 vs 570 TFLOP/s isolated,
-// 28.95 vs 28.08 ms in the step), 8 waves as 2 K-waves of 96 x 48 (BIG=5: 491), a second register set so that the global
-// loads of chunk k+2 fly under chunk k (472: the loop does not wait on vmcnt) -- the ISA shows what it waits on: the
-// compiler's schedule reads each A fragment ONE group of 3 MFMAs (48 cycles) ahead of its use, and a transposing LDS
-// read takes longer than that, 12 times per chunk, with no second wave on the SIMD to cover it. FP (below) reads the
-// fragments of K-step s+1 under the MFMAs of K-step s instead.
+// its L2). For the stem (C = 16) a block covers all 9 taps at once: the X tile is [pixel][9 x 16 "virtual channels"]
+// (an im2col slice built by the loader, every 16-byte chunk with its own tap offset and bounds test), so dY is read once
+// and a wave gets 3 x 9 MFMAs per 32-pixel step instead of 3 x 1.
+// wgrad_dma_kernel: the same GEMM as a producer / consumer workgroup -- two producer waves issue LDS-DMA loads straight into
+// the sub-tiles, four consumer waves only read fragments and issue MFMAs (192 x 192 block tile, one workgroup per CU).
+// The forms that were tried and lost (row-of-taps, fragment pipelining, 128-pixel chunks, 8-wave tiles, register-staged
+// producers, non-atomic slices) are recorded in NOTES.md.
 #include "y5m_conv.h"
 #include <stdlib.h>
 
 #define WG_THREADS 256
 #ifndef Y5M_EXP
-#define Y5M_EXP 0     // timing-only ablation builds (tools/exp_wgrad.sh): results are WRONG by construction
+#define Y5M_EXP 0
 #endif
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));

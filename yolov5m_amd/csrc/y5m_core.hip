@@ -14,6 +14,33 @@ extern "C" void y5m_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// 32-bit fill as a KERNEL launch. The library never calls hipMemsetAsync: inside a captured hipGraph a memset is its own
+// node type (not a kernel node), and this code base keeps every node of its graphs a kernel node (NOTES.md, "graph replay").
+__global__ void y5m_fill32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n, int vec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (vec) {                                  // 16-byte aligned base: 16-byte stores + scalar tail
+        const size_t n4 = n / 4;
+        uint4* p4 = reinterpret_cast<uint4*>(p);
+        const uint4 v4 = make_uint4(v, v, v, v);
+        for (size_t j = i; j < n4; j += stride) p4[j] = v4;
+        for (size_t j = n4 * 4 + i; j < n; j += stride) p[j] = v;
+    } else {
+        for (size_t j = i; j < n; j += stride) p[j] = v;
+    }
+}
+int y5m_fill32(void* p, uint32_t v, size_t n_words, hipStream_t st) {
+    if (n_words == 0) return Y5M_OK;
+    if ((reinterpret_cast<uintptr_t>(p) & 3) != 0) { y5m_set_error("y5m_fill32: pointer must be 4-byte aligned"); return Y5M_EINVAL; }
+    const int vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    size_t blocks = ((vec ? n_words / 4 : n_words) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(y5m_fill32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), v, n_words, vec);
+    Y5M_CHECK_LAUNCH("y5m_fill32_kernel");
+    return Y5M_OK;
+}
+
 extern "C" const char* y5m_version(void) { return "y5m-gfx950 0.1"; }
 extern "C" const char* y5m_last_error(void) { return g_err; }
 

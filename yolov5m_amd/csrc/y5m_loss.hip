@@ -420,7 +420,7 @@ static int run_loss(const float* const p[3], float* const grad[3], const float* 
         S.dense = dense ? dense[s] : nullptr;
         if (!S.p) { S.nblk = 0; S.cells = 0; continue; }
         max_blk = nblk[s] > max_blk ? nblk[s] : max_blk;
-        if (hipMemsetAsync(S.owner, 0xFF, (size_t)S.cells * 4, st) != hipSuccess) { y5m_set_error("memset owner"); return Y5M_ELAUNCH; }
+        if (y5m_fill32(S.owner, 0xFFFFFFFFu, (size_t)S.cells, st) != Y5M_OK) return Y5M_ELAUNCH;
     }
     const dim3 rgrid((unsigned)((cap + 3) / 4), 3);
     if (nt_max > 0) {

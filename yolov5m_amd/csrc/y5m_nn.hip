@@ -1243,7 +1243,7 @@ extern "C" int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny,
                                   float* dbias, int dtype, void* stream) {
     Y5M_REQUIRE(ldp <= 256 && ldp >= naxs * nch, "head dims: naxs*nch <= ldp <= 256");
     hipStream_t st = y5m_stream(stream);
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)naxs * nch * 4, st) != hipSuccess) { y5m_set_error("memset dbias"); return Y5M_ELAUNCH; }
+    if (dbias && y5m_fill32(dbias, 0u, (size_t)naxs * nch, st) != Y5M_OK) return Y5M_ELAUNCH;
     const int64_t M = (int64_t)B * ny * nx;
     const unsigned grid = (unsigned)(M < 4096 ? M : 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_kernel<T>, dim3(grid), dim3(256), 0, st, dlogits, B, naxs,
@@ -1334,7 +1334,7 @@ extern "C" int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* ow
     Y5M_REQUIRE(ldp <= 256 && ldp >= naxs * nch && ldp % 4 == 0, "head dims: naxs*nch <= ldp <= 256, ldp % 4 == 0");
     Y5M_REQUIRE(owner && gobj && bagg && count && cap >= 0, "owner / objectness-gradient / target-row tables missing");
     hipStream_t st = y5m_stream(stream);
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)naxs * nch * 4, st) != hipSuccess) { y5m_set_error("memset dbias"); return Y5M_ELAUNCH; }
+    if (dbias && y5m_fill32(dbias, 0u, (size_t)naxs * nch, st) != Y5M_OK) return Y5M_ELAUNCH;
     const int64_t M = (int64_t)B * ny * nx;
     const unsigned grid = (unsigned)((M + 255) / 256);
     DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_obj_kernel<T>, dim3(grid), dim3(256), 0, st, gobj, B, naxs,

@@ -110,6 +110,10 @@ class Engine:
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
+        # Y5M_WGRAD_SERIAL (experiment): weight gradients that run INLINE on the main stream instead of on the forked one --
+        # bit 0: the 3x3 layers with both channel counts a multiple of 192, bit 1: every 3x3 layer, bit 2: every layer
+        self.serial_sel = int(os.environ.get("Y5M_WGRAD_SERIAL", "0"))
+        self.ablate = set(x for x in os.environ.get("Y5M_ABLATE", "").split(",") if x)
         self.fork_mode = int(os.environ.get("Y5M_WGRAD_FORK", "1"))   # 2: fork behind the next BatchNorm backward's reduce launch
         # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
         # so it runs ahead of the side stream instead of ping-ponging with it (each cross-stream wait costs
@@ -223,6 +227,7 @@ class Engine:
         if self.training:
             lay.y = torch.zeros((M * cout,), dtype=self.tdt, device=self.dev)
             lay.y_ptr, lay.y_ld = lay.y.data_ptr(), cout
+            lay.y_view = (lay.y, 0, cout)         # (tensor, first channel, pixel stride): the raw conv output for tests / tools
             dest.producer = lay
             self._consume(x)
             self._consume(res)
@@ -576,6 +581,7 @@ class Engine:
             lay.kk, lay.ss, lay.pp, lay.M, lay.Ho, lay.Wo = 1, 1, 0, M, x.H, x.W
             lay.z, lay.off = dest, off
             lay.y_ptr, lay.y_ld = y2.data_ptr() + off * esz, N2
+            lay.y_view = (y2, off, N2)
             dest.producer = lay
             lay.bn = torch.zeros((4, cout), dtype=torch.float32, device=self.dev)
             rows = cout if off == 0 else Np2 - cout          # the second job also zero-fills the row padding
@@ -932,8 +938,21 @@ class Engine:
         """Run `fns` on the side stream, ordered after everything enqueued so far on the current stream
         (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
         hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
+        inline = not self.overlap
+        sel = self.serial_sel
+        if wa is not None and self.ablate:
+            # Y5M_ABLATE (TIMING ONLY, gradients WRONG): drop weight-gradient launches by class -- parameters then only see weight
+            # decay, the activations / gradients flowing through the step keep their values (tools/ab_step.sh)
+            taps = wa.th * wa.tw
+            if ("wgrad_pw" in self.ablate and taps == 1) or ("wgrad_3x3" in self.ablate and taps > 1):
+                fns = []
+        if wa is not None and sel:
+            taps = wa.th * wa.tw
+            wide = taps > 1 and wa.C % 192 == 0 and wa.N % 192 == 0
+            inline = inline or bool((sel & 4) or ((sel & 2) and taps > 1) or ((sel & 1) and wide))
+
         def run():
-            if not self.overlap:
+            if inline:
                 for f in fns:
                     f()
                 return
@@ -942,9 +961,16 @@ class Engine:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
+            tls = getattr(self, "_tl_side", None)      # profile_step(overlapped=True): time the launch on ITS stream
             with torch.cuda.stream(side):
+                if tls is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
                 for f in fns:
                     f()
+                if tls is not None:
+                    e1.record(side)
+                    tls.append((run, e0, e1))
                 done = torch.cuda.Event()
                 done.record(side)
             self._pending[slot] = done

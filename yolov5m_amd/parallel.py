@@ -73,28 +73,92 @@ def make_buckets(numel, boundaries, target_bytes=32 << 20):
 
 
 class GradAllReduce:
-    """SUM all-reduce of a flat gradient buffer, whole or bucket by bucket."""
+    """SUM all-reduce of a flat gradient buffer, whole (`hook(flat)`) or bucket by bucket (`launch` / `wait`).
 
-    def __init__(self, world_size=None, group=None):
+    Bucketed form on GPU tensors: every bucket is issued from a dedicated COMMUNICATION stream that first waits for an
+    event recorded on the compute stream (everything enqueued so far -- the backward segment that finished the bucket),
+    so the compute stream itself never waits for a collective until `wait()`, right before the optimizer. With
+    `timing=True` each bucket carries an event pair on the communication stream (ready -> reduced: queueing behind the
+    previous bucket included) and `wait()` is bracketed by a pair on the compute stream: that pair's elapsed time is the
+    EXPOSED part of the exchange (`stats()`, read by bench.py after a synchronize).
+    `force=True` runs the collectives with a single rank too (the 1-GPU RCCL smoke of the overlapped schedule)."""
+
+    def __init__(self, world_size=None, group=None, timing=False, force=False):
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.timing, self.force = timing, force
         self.pending = []
+        self._comm = None
+        self._evs = []           # per bucket index: (ready, start, end), created once and re-recorded every step
+        self._wait_evs = None
+        self._buckets = []       # (lo, hi) of the last step's launches, in launch order
+
+    @property
+    def active(self):
+        return self.world > 1 or (self.force and dist.is_initialized())
 
     def __call__(self, flat):
         """blocking (stream-ordered on GPU) all-reduce of the whole buffer"""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
     def launch(self, flat, lo, hi):
         """asynchronous all-reduce of flat[lo:hi] (call after the producing kernels were enqueued)"""
-        if self.world > 1:
+        if not self.active:
+            return
+        if not flat.is_cuda:
             self.pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        i = len(self.pending)
+        if i == 0:
+            self._buckets = []
+        self._buckets.append((lo, hi))
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=flat.device)
+        while len(self._evs) <= i:
+            self._evs.append(tuple(torch.cuda.Event(enable_timing=self.timing) for _ in range(3)))
+        ready, start, end = self._evs[i]
+        main = torch.cuda.current_stream(flat.device)
+        ready.record(main)
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(ready)
+            if self.timing:
+                start.record(self._comm)
+            w = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()            # nccl: the communication stream waits for the backend's stream (no host block); gloo: host wait
+            end.record(self._comm)
+        self.pending.append(end)
 
     def wait(self):
-        for w in self.pending:
-            w.wait()
+        """the current stream waits for every launched bucket"""
+        if not self.pending:
+            return
+        if not isinstance(self.pending[0], torch.cuda.Event):
+            for w in self.pending:
+                w.wait()
+            self.pending = []
+            return
+        main = torch.cuda.current_stream()
+        if self.timing:
+            if self._wait_evs is None:
+                self._wait_evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._wait_evs[0].record(main)
+        for end in self.pending:
+            main.wait_event(end)
+        if self.timing:
+            self._wait_evs[1].record(main)
         self.pending = []
+
+    def stats(self):
+        """timing of the LAST step's exchange (call after torch.cuda.synchronize(); needs timing=True): per bucket
+        (megabytes, ms from "gradients final" to "reduced" on the communication stream) and the milliseconds the compute
+        stream spent waiting for the exchange in wait()."""
+        if not self.timing or self._wait_evs is None or not self._buckets:
+            return None
+        b = [{"MB": round((hi - lo) * 4 / 1e6, 2), "ms": round(self._evs[i][1].elapsed_time(self._evs[i][2]), 3)}
+             for i, (lo, hi) in enumerate(self._buckets)]
+        return {"buckets": b, "allreduce_exposed_ms": round(self._wait_evs[0].elapsed_time(self._wait_evs[1]), 3)}
 
 
 def broadcast_parameters(model, src=0, group=None):

@@ -225,7 +225,8 @@ class NativeTrainStep:
         self.model._nbt += 1
         if self.accumulate > 1:
             return self._step_accumulate(eng)
-        if self.overlap and hasattr(self.grad_hook, "launch"):
+        self._check_hyper()
+        if self.overlap and hasattr(self.grad_hook, "launch") and getattr(self.grad_hook, "active", True):
             return self._step_overlapped(eng)
         if not self.use_graph:
             self._enqueue_fb(eng)
@@ -279,7 +280,8 @@ class NativeTrainStep:
             ent = self._fb_graphs.get(eng.key)
             for k in [k for k, e in self._fb_graphs.items() if e[0].released]:
                 del self._fb_graphs[k]
-            graphs = ent[1] if ent is not None and ent[0] is eng and self._opt_graph is not None else None
+            graphs = ent[1] if (ent is not None and ent[0] is eng and ent[2] == "segments"
+                                and self._opt_graph is not None) else None
         if self.use_graph and graphs is None:
             # eager warm-up step (this call's step), then capture one graph per segment
             for i in range(len(ks)):
@@ -300,7 +302,7 @@ class NativeTrainStep:
                     with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                         self._optimizer()
                     self._opt_graph = g2
-                self._fb_graphs[eng.key] = (eng, gs)
+                self._fb_graphs[eng.key] = (eng, gs, "segments")
             except Exception as e:
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
@@ -323,13 +325,21 @@ class NativeTrainStep:
             self._optimizer()
         return self.loss_out
 
+    def _check_hyper(self):
+        """the captured optimizer graph holds lr / betas / eps / weight decay / max_norm as kernel arguments: drop it (and the
+        plans' graphs, which are only handed out together with it) when any of them was changed on this object"""
+        h = (self.lr, tuple(self.betas), self.eps, self.wd, self.max_norm)
+        if getattr(self, "_hyper", h) != h:
+            self._fb_graphs, self._opt_graph = {}, None
+        self._hyper = h
+
     def _graph_for(self, eng):
         """the captured forward+loss+backward graph of this plan, or None. Entries of plans the model has evicted
         (Engine.released) are dropped here: their buffers are gone."""
-        for k in [k for k, (e, _g) in self._fb_graphs.items() if e.released]:
+        for k in [k for k, e in self._fb_graphs.items() if e[0].released]:
             del self._fb_graphs[k]
         ent = self._fb_graphs.get(eng.key)
-        if ent is not None and ent[0] is eng and self._opt_graph is not None:
+        if ent is not None and ent[0] is eng and ent[2] == "whole" and self._opt_graph is not None:
             return ent[1]
         return None
 
@@ -345,7 +355,7 @@ class NativeTrainStep:
                 with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._optimizer()
                 self._opt_graph = g2
-            self._fb_graphs[eng.key] = (eng, g1)
+            self._fb_graphs[eng.key] = (eng, g1, "whole")
         except Exception as e:                           # capture is an optimisation, never a requirement
             import warnings
             warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
@@ -426,20 +436,35 @@ class NativeTrainStep:
         self.d_step.fill_(step)
         self._fb_graphs, self._opt_graph = {}, None   # captured scalars (lr, betas) may have changed
 
-    def profile_step(self, images, targets, detail=False):
+    def profile_step(self, images, targets, detail=False, overlapped=False):
         """One EAGER step with a HIP event pair around every launch (recorded on the launch stream).
         Returns {kernel family: (total ms, launches)}; with detail=True also the list of (ms, y5m_conv_args) of
-        every forward-conv / data-gradient launch, for per-shape rooflines."""
+        every forward-conv / data-gradient launch, for per-shape rooflines.
+        overlapped=False: the forked weight gradients run inline (serialised), so the per-family times add up.
+        overlapped=True: the step's own schedule -- weight gradients on the forked stream next to the main stream's
+        BatchNorm backward / data gradients, each launch timed by events on the stream it runs on (what a launch costs
+        INSIDE the step; the durations then overlap and do not add up to the step time)."""
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
         tl = []
-        saved, eng.overlap = eng.overlap, False      # serialise the side stream so per-family times add up
+        saved = eng.overlap
+        side_tl = [] if overlapped else None
+        if not overlapped:
+            eng.overlap = False                      # serialise the side stream so per-family times add up
+        eng._tl_side = side_tl
         try:
             self._enqueue_fb(eng, tl)
             self._optimizer(tl)
             torch.cuda.synchronize()
         finally:
             eng.overlap = saved
+            eng._tl_side = None
+        if side_tl:
+            # a forked launch's main-stream pair only brackets its ENQUEUE: take the pair recorded on the forked stream
+            by_fn = {id(fn): (e0, e1) for fn, e0, e1 in side_tl}
+            items_ = list(eng.pack) + list(eng.fwd) + [None] + list(eng.bwd) + [None]
+            tl = [(kind, *by_fn.get(id(item[0]), (e0, e1))) if item is not None else (kind, e0, e1)
+                  for (kind, e0, e1), item in zip(tl, items_)]
         fam = {}
         for kind, e0, e1 in tl:
             ms, n = fam.get(kind, (0.0, 0))
