@@ -93,30 +93,6 @@ def cpu_baseline(B=4, size=640, steps=3):
                       f"({os.cpu_count()} logical CPUs)"}
 
 
-def wgrad_forms_leg():
-    """The weight-gradient kernel forms ALONE on the chip (tools/conv_bench.py in child processes: the form is chosen by
-    Y5M_WGRAD_PC, read once per process): the default 4-wave wgrad_kernel -- the roofline headline above, measured there
-    INSIDE the step -- and wgrad_dma_kernel (LDS-DMA producer waves + software-pipelined consumer waves), which is faster
-    alone and slower inside the overlapped step. HIP events around 50 launches, B=64, bf16."""
-    import re
-    import subprocess
-    shapes = {"192->192 3x3 @40x40": "64 192 40 40 192 3 1 50", "384->768 3x3 stride 2 @40x40": "64 384 40 40 768 3 2 50"}
-    out = {}
-    for form, pc in (("wgrad_kernel (default)", "0"), ("wgrad_dma_kernel (Y5M_WGRAD_PC=57)", "57")):
-        for name, args_ in shapes.items():
-            try:
-                env = dict(os.environ, Y5M_WGRAD_PC=pc)
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_bench.py"), "wgrad"] + args_.split(),
-                                   env=env, capture_output=True, text=True, timeout=180)
-                m = re.search(r"([0-9.]+) us\s+([0-9.]+) TF/s", r.stdout)
-                if m:
-                    out.setdefault(form, {})[name] = {"us": float(m.group(1)), "TFLOPs": float(m.group(2)),
-                                                      "frac": round(float(m.group(2)) / PEAK_BF16_TFLOPS, 4)}
-            except Exception:
-                pass
-    return out
-
-
 def first_loss_check(first_loss, B, S, rank):
     """the first step's ComputeLoss next to the REAL reference's f32 value for the same inputs and initial weights
     (tests/golden/g13_precision.npz, made by tests/golden/make_golden.py from /root/reference; B = 64 @ 640x640, rank 0)"""
@@ -380,22 +356,22 @@ def main():
                            "last_step_max_over_ranks": xstats}
     if not args.no_roofline:
         fams = {}
-        cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
+        cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0], "fused_pw_bwd": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
         esz = 2 if args.dtype == "bf16" else 4
         kernels, insitu = {}, {}
         for _ in range(2):
             # the step's OWN schedule (weight gradients on the forked stream next to the main stream's kernels), every
             # launch timed by HIP events on the stream it runs on: what a launch costs inside the step
             _f, _c, kern = step.profile_step(images, targets, detail="kernels", overlapped=True)
-            for name, ms_, fl in kern:
-                k = insitu.setdefault(name, [0.0, 0.0, 0])
-                k[0] += ms_; k[1] += fl; k[2] += 1
+            for name, ms_, fl, *by in kern:
+                k = insitu.setdefault(name, [0.0, 0.0, 0, 0.0])
+                k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
         for _ in range(2):
             # the same launches with the forked stream serialised: per-family times that add up
             fam, convs, kern = step.profile_step(images, targets, detail="kernels")
-            for name, ms_, fl in kern:
-                k = kernels.setdefault(name, [0.0, 0.0, 0])
-                k[0] += ms_; k[1] += fl; k[2] += 1
+            for name, ms_, fl, *by in kern:
+                k = kernels.setdefault(name, [0.0, 0.0, 0, 0.0])
+                k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
             for k, (m_, n_) in fam.items():
                 a, b = fams.get(k, (0.0, 0))
                 fams[k] = (a + m_, b + n_)
@@ -404,6 +380,14 @@ def main():
                 c[0] += ms_
                 c[1] += 2.0 * a.M * a.N * a.K
                 c[2] += float(a.M) * (a.K / (a.th * a.tw) + a.N) * esz + float(a.N) * a.K * esz
+                c[3] += 1
+            for ms_, a in step.last_bwd_pw:
+                # fused pointwise backward: algorithmic bytes = dz + y (N channels each) + x + dx (C channels each; + the
+                # accumulation source when dx is added onto a tensor), 2 bytes per element
+                c = cls["fused_pw_bwd"]
+                c[0] += ms_
+                c[1] += 4.0 * a.M * a.N * a.C
+                c[2] += float(a.M) * (2 * a.N + (3 if (a.accumulate or a.res) else 2) * a.C) * esz
                 c[3] += 1
         eng = model._engine_for(images)
         fwd_flops = eng.conv_flops()
@@ -418,25 +402,36 @@ def main():
         # step's own overlapped schedule (HIP events on the launching stream); `frac` is that in-situ figure, the
         # serialised one (forked stream run inline) sits beside it; the conv family and the per-kernel table follow
         ranked = sorted(insitu.items(), key=lambda kv: -kv[1][0])
-        dom_name, (dom_ms, dom_fl, dom_n) = ranked[0]
-        dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12
-        ser_ms, ser_fl, ser_n = kernels.get(dom_name, (dom_ms, dom_fl, dom_n))
-        ser_tf = ser_fl / (ser_ms * 1e-3) / 1e12
+        dom_name, (dom_ms, dom_fl, dom_n, dom_by) = ranked[0]
+        ser_ms, ser_fl, ser_n, ser_by = kernels.get(dom_name, (dom_ms, dom_fl, dom_n, dom_by))
+        hbm = dom_by > 0            # a kernel that carries algorithmic BYTES (the fused pointwise backward) is HBM-bound
+        if hbm:
+            dom_ach, ser_ach, peak, unit = dom_by / (dom_ms * 1e-3) / 1e9, ser_by / (ser_ms * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
+        else:
+            dom_ach, ser_ach, peak, unit = dom_fl / (dom_ms * 1e-3) / 1e12, ser_fl / (ser_ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
         traffic, traffic_src = pmc_traffic(dom_name)
+
+        def row(n_, v):
+            r_ = {"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
+                  "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                  "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                  "ms_per_step_serialised": round(kernels.get(n_, v)[0] / 2, 3)}
+            if v[3] > 0:
+                r_.update(bound="hbm", achieved_GBps=round(v[3] / (v[0] * 1e-3) / 1e9, 1),
+                          frac=round(v[3] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4))
+            return r_
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom_name,
-            "achieved": round(dom_tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(dom_tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "bound": "hbm" if hbm else "mfma", "kernel": dom_name,
+            "achieved": round(dom_ach, 2), "peak": peak, "unit": unit,
+            "frac": round(dom_ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "timing": "HIP events around every launch on its own stream, inside the step's overlapped schedule (eager pass)",
             "launches_per_step": dom_n // 2, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
             "algorithmic_gflop_per_launch": round(dom_fl / max(dom_n, 1) / 1e9, 2),
+            "algorithmic_MB_per_launch": round(dom_by / max(dom_n, 1) / 1e6, 2) if hbm else None,
             "share_of_step_ms": round(dom_ms / 2, 3),
-            "achieved_serialised": round(ser_tf, 2), "frac_serialised": round(ser_tf / PEAK_BF16_TFLOPS, 4),
+            "achieved_serialised": round(ser_ach, 2), "frac_serialised": round(ser_ach / peak, 4),
             "avg_launch_us_serialised": round(ser_ms * 1e3 / max(ser_n, 1), 2),
-            "by_kernel": [{"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
-                           "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
-                           "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                           "ms_per_step_serialised": round(kernels.get(n_, v)[0] / 2, 3)} for n_, v in ranked[:8]],
+            "by_kernel": [row(n_, v) for n_, v in ranked[:8]],
             "conv_family": {"what": "forward conv + data gradient, all y5m_conv launches of one step",
                             "achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                             "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
@@ -455,13 +450,13 @@ def main():
                                          "achieved_GBps": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6, 1),
                                          "achieved_TFLOPs": round(cls["pointwise"][1] / max(cls["pointwise"][0], 1e-9) / 1e9, 1),
                                          "frac": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
+                "fused_pointwise_backward(bn apply + dgrad + wgrad)": {
+                    "bound": "hbm", "launches_per_step": cls["fused_pw_bwd"][3] // 2, "ms_per_step": round(cls["fused_pw_bwd"][0] / 2, 3),
+                    "achieved_GBps": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6, 1),
+                    "achieved_TFLOPs": round(cls["fused_pw_bwd"][1] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e9, 1),
+                    "frac": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
             },
         }
-    if world == 1 and not args.no_roofline:
-        try:
-            out["roofline"]["wgrad_forms_alone_on_the_chip"] = wgrad_forms_leg()
-        except Exception:
-            pass
     if world == 1 and not args.no_detect:
         del step, images
         model._engines = {}

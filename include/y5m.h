@@ -255,17 +255,39 @@ typedef struct {
     int32_t ksplit;      /* pixel-range splits (<=0: library picks)                              */
     int32_t tiles_n, tiles_c;   /* filled by the library                                         */
     const void* zeros;   /* >= 16 zero bytes in device memory (see y5m_conv_args)                 */
-    int32_t slices_cap;  /* 0: split-K partial tiles are ADDED into dwgt [N][lddw] with f32 atomics (dwgt zeroed by the
-                            caller). > 0: NON-ATOMIC mode: dwgt holds slices_cap slices of N*lddw floats and pixel
-                            range k writes its partial tile into slice k with plain stores (no zeroing needed, at most
-                            slices_cap ranges); y5m_unpack_wgrad_slices sums the slices in a fixed order. Pointwise
-                            layers are bound by the atomics otherwise (their output tiles are tiny). */
+    int32_t reserved0;   /* must be 0 */
     int32_t pad_;
 } y5m_wgrad_args;
 int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
 int y5m_wgrad_kernel_name(const y5m_wgrad_args* args, int dtype, char* buf, int n);   /* see y5m_conv_kernel_name */
-/* the number of pixel ranges (= slices written in non-atomic mode) y5m_wgrad will use for these arguments */
-int y5m_wgrad_slices(const y5m_wgrad_args* args, int dtype);
+
+/* Fused backward of a pointwise (1x1, stride 1) CBL with N == C in {48, 96, 192} channels, bf16 (csrc/y5m_bwd_pw.hip;
+ * reference model.py:12-28 backward): dy = BatchNorm+SiLU backward of (dz, y) is formed in registers and never stored;
+ * dx (+)= dy . W; dW += dy^T . x (f32 atomics); dgamma / dbeta are written. The BatchNorm reduction must have been
+ * accumulated into seg[].acc by y5m_bn_bwd_fused_phase(..., phase = 1) ahead of this call. Up to two BatchNorm segments
+ * side by side on the output channels (the merged C3 pair: two layers, one launch). */
+typedef struct {
+    int32_t c0, cn;            /* first output channel and channel count of this segment (c0 of segment 0 is 0)          */
+    int32_t lddz, pad_;
+    const void* dz;            /* [M][lddz] gradient wrt THIS segment's CBL output (channel 0 of the segment)               */
+    const double* acc;         /* [y5m_bn_acc_slots()][2][cn] f64 rows of the reduce pass                                 */
+    const float* scale; const float* shift; const float* mean; const float* invstd;   /* [cn], forward statistics       */
+    float* dgamma; float* dbeta;                                                       /* [cn] outputs (may be NULL)     */
+    float* dw;                 /* [cn][lddw] f32 weight gradient of THIS segment's layer, accumulated atomically           */
+} y5m_bwd_pw_seg;
+typedef struct {
+    const void* y; const void* x;   /* [M][ldy] raw conv output (all segments side by side), [M][ldx] conv input */
+    const void* wd;            /* data-gradient weight rows [C][Kp] (y5m_pack_weights mode 1), NULL with dx == NULL       */
+    void* dx;                  /* [M][lddx] gradient wrt the conv input, or NULL                                           */
+    const void* res;           /* accumulation source [M][ldres] (dx = res + dy.W) or NULL (accumulate: dx += dy.W)        */
+    int64_t M;
+    int32_t ldy, ldx, Kp, lddx, ldres, lddw;
+    int32_t N, C;              /* output / input channels (N == C)                                                         */
+    int32_t accumulate, act, nseg;
+    y5m_bwd_pw_seg seg[2];
+} y5m_bwd_pw_args;
+int y5m_bwd_pw(const y5m_bwd_pw_args* args, int dtype, void* stream);
+int y5m_bwd_pw_eligible(const y5m_bwd_pw_args* args, int dtype);    /* 1 when y5m_bwd_pw accepts these arguments */
 
 /* Weight layout conversion. master f32 [Cout][Cin][KH][KW] (the reference state_dict layout,
  * model.py:15) -> packed K-contiguous rows in compute dtype.
@@ -289,10 +311,6 @@ int y5m_pack_weights_batched(const y5m_pack_job* d_jobs, int njobs, int64_t tota
 /* packed f32 gradient [Cout][ldg] (mode 0 or 2 ordering) -> [Cout][Cin][KH][KW] */
 int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int KW, int mode, int ldg, float* dst,
                      void* stream);
-/* the same from `nslices` partial gradients laid out slice_stride floats apart (non-atomic y5m_wgrad), summed in
- * slice order */
-int y5m_unpack_wgrad_slices(const float* gp, int nslices, int64_t slice_stride, int Cout, int Cin, int KH, int KW, int mode,
-                            int ldg, float* dst, void* stream);
 /* Input stage on the device (utils/training_utils.py:98 `images.float()/255` and :11-28 multi_scale):
  * uint8 (B,3,Hs,Ws) -> f32 (B,3,H,W) = F.interpolate(img/255, (H,W), "bilinear", align_corners=False);
  * Hs==H && Ws==W is the plain /255 conversion. */

@@ -350,7 +350,7 @@ def g14_nms_crosspin():
     out, names = {}, []
     for N, iou_thr, seed in ((64, 0.45, 1), (65, 0.6, 2), (1000, 0.45, 3), (1000, 0.6, 4), (5000, 0.45, 5), (5000, 0.6, 6)):
         rng = np.random.default_rng(1400 + seed)
-        span = {64: 200, 65: 200, 1000: 500, 5000: 900}[N]
+        span = {64: 200, 65: 200, 1000: 400, 5000: 420}[N]      # (dense: the reference's greedy loop is O(N * kept) torch calls)
         while True:
             x1 = np.floor(rng.uniform(0, span, N) * 4) / 4
             y1 = np.floor(rng.uniform(0, span, N) * 4) / 4

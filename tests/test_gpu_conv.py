@@ -98,24 +98,10 @@ HALO_CASES = [
 
 
 def _halo_expected(Cin, N):
-    """the library's dispatch rule (y5m_conv_halo.hip halo_geom): 192-channel tiles by default, the 96-channel tile only
-    with Y5M_CONV_HALO=2 (test_halo_96_channel_tile_subprocess runs this file's halo tests that way)"""
+    """the library's dispatch rule (y5m_conv_halo.hip halo_geom): 192-channel tiles (Y5M_CONV_HALO=0 turns the kernel off)"""
     import os
     lvl = int(os.environ.get("Y5M_CONV_HALO", "1"))
-    wide = N % 192 == 0 and Cin % 64 == 0
-    return "halo" if (lvl >= 1 and wide) or (lvl >= 2 and N % 96 == 0) else None
-
-
-def test_halo_96_channel_tile_subprocess():
-    """the 96-channel tile of the halo kernel is off by default (slower than the tiled kernel on N = 96); its code path --
-    32-channel last slab, two weight pieces per wave with the dummy-region redirect -- is checked in a child process"""
-    import os, subprocess, sys
-    if os.environ.get("Y5M_CONV_HALO") == "2":
-        pytest.skip("already the child")
-    env = dict(os.environ, Y5M_CONV_HALO="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "halo_forward or halo_dgrad"], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return "halo" if lvl >= 1 and N % 192 == 0 and Cin % 64 == 0 else None
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
@@ -398,9 +384,7 @@ def test_conv_wgrad(case, dtype):
     assert _relerr(got, w.grad) < TOL[dtype], (case, dtype, _relerr(got, w.grad))
 
 
-# ---- wide-layer weight gradients (the 192 x 96 and 96 x 96 block tiles of wgrad_kernel, and their producer / consumer
-# forms wgrad_pc_kernel / wgrad_dma_kernel: Y5M_WGRAD_PC, bit 0 = 192 x 96 tile, bit 1 = 96 x 96 tile, bit 3 = 192 x 192 tile,
-# bits 4 / 5 = LDS-DMA staging from 4 / 2 producer waves, bit 6 = from one). Ragged pixel counts (tail chunk),
+# ---- wide-layer weight gradients: the 192 x 96 and 96 x 96 block tiles of wgrad_kernel. Ragged pixel counts (tail chunk),
 # widths that are not a multiple of the 64-pixel chunk (rows and images change inside a chunk), stride 2, channel counts
 # that leave a partial channel tile, and enough pixels for several chunks per split-K range.
 WGRAD_WIDE_CASES = [
@@ -411,12 +395,9 @@ WGRAD_WIDE_CASES = [
     (5, 96, 40, 40, 96, 3, 1, 1),
     (2, 144, 10, 14, 384, 3, 1, 1),
     (16, 192, 40, 40, 192, 3, 1, 1),
+    (2, 192, 9, 13, 384, 3, 2, 1),
+    (3, 384, 10, 10, 384, 3, 1, 1),
 ]
-
-
-def _wgrad_pc_bits():
-    import os
-    return int(os.environ.get("Y5M_WGRAD_PC", "0"))
 
 
 @pytest.mark.parametrize("case", WGRAD_WIDE_CASES)
@@ -429,30 +410,58 @@ def test_conv_wgrad_wide_layers(case):
     dy = _q(_rand(tuple(y.shape), 23), "bf16")
     y.backward(dy)
     got = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, "bf16").cpu()
-    bits = _wgrad_pc_bits()
-    wide = Cout % 192 == 0
-    if (bits & 1 and wide) or (bits & 2 and not wide) or (bits & 8 and wide and Cin % 192 == 0):
-        assert ops.LAST_WGRAD_KERNEL.startswith(("wgrad_pc_kernel", "wgrad_dma_kernel")), ops.LAST_WGRAD_KERNEL
-        if bits & 48 and Cin % 96 == 0 and Cout % 96 == 0:        # LDS-DMA producers want full channel tiles
-            assert ops.LAST_WGRAD_KERNEL.startswith("wgrad_dma_kernel"), ops.LAST_WGRAD_KERNEL
+    assert ops.LAST_WGRAD_KERNEL.startswith("wgrad_kernel"), ops.LAST_WGRAD_KERNEL
     assert _relerr(got, w.grad) < TOL["bf16"], (case, ops.LAST_WGRAD_KERNEL, _relerr(got, w.grad))
 
 
-@pytest.mark.parametrize("form", ["pc", "dma4", "dma2", "dma1"])
-def test_wgrad_other_form_subprocess(form):
-    """the weight-gradient forms that are NOT the default of this build (producer / consumer workgroups with register
-    staging, with LDS-DMA staging from four / two / one producer waves; or the 4-wave kernel when one of those is the default) on
-    the same cases, in a child process (the knob is read once per process)"""
-    import os, subprocess, sys
-    if os.environ.get("Y5M_WGRAD_TEST_CHILD") == "1":
-        pytest.skip("already the child")
-    other = {"pc": "11", "dma4": "27", "dma2": "59", "dma1": "89"}[form]
-    if _wgrad_pc_bits() == int(other):
-        other = "0"
-    env = dict(os.environ, Y5M_WGRAD_PC=other, Y5M_WGRAD_TEST_CHILD="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "wgrad_wide or test_conv_wgrad"], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+# ---- fused pointwise backward (csrc/y5m_bwd_pw.hip): BatchNorm+SiLU backward apply + data gradient + weight gradient of a
+# 1x1 CBL in one launch, against torch autograd of the same layer on the same bf16 operands. Channel counts 48 / 96 / 192
+# (the three tile geometries), pixel counts that leave a tile tail and that give some workgroups no tile at all, two
+# BatchNorm segments (the merged C3 pair), plain / accumulate-onto / separate-source epilogues.
+BWD_PW_CASES = [
+    # B, C, H, W, split
+    (2, 48, 20, 24, None),
+    (3, 96, 17, 19, None),
+    (2, 192, 12, 10, None),
+    (5, 192, 40, 40, 96),
+    (4, 96, 80, 80, 48),
+    (2, 48, 160, 160, None),
+    (64, 192, 20, 20, None),
+]
+
+
+@pytest.mark.parametrize("mode", ["plain", "init", "src"])
+@pytest.mark.parametrize("case", BWD_PW_CASES)
+def test_bwd_pw_fused(case, mode):
+    from yolov5m_amd import ops
+    B, C, H, W, split = case
+    x = _q(_rand((B, C, H, W), 31, -1, 1), "bf16")
+    w = _rand((C, C, 1, 1), 32, -0.25, 0.25)
+    wq = _q(w, "bf16")
+    gamma, beta = _rand((C,), 33, 0.5, 1.5), _rand((C,), 34, -0.3, 0.3)
+    yq = _q(F.conv2d(x, wq), "bf16").requires_grad_(True)          # the raw conv output as the engine stores it
+    dz = _q(_rand((B, C, H, W), 35, -1, 1), "bf16")
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.silu(F.batch_norm(yq, None, None, g_, b_, True, 0.03, 1e-3))
+    z.backward(dz)
+    dyq = _q(yq.grad, "bf16")                                       # dy reaches both GEMMs rounded to bf16
+    dx_ref = F.conv_transpose2d(dyq, wq)
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dyq)
+    extra = _q(_rand((B, C, H, W), 36, -1, 1), "bf16") if mode != "plain" else None
+    if extra is not None:
+        dx_ref = dx_ref + extra
+    mean = yq.detach().mean((0, 2, 3))
+    var = yq.detach().var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    dev = lambda t: t.to(DEV)
+    dx, dw, dg, db = ops.bwd_pw(dev(dz), dev(yq.detach()), dev(x), dev(w), dev(scale), dev(shift), dev(mean), dev(invstd), split=split,
+                                init=dev(extra) if mode == "init" else None, src=dev(extra) if mode == "src" else None)
+    assert _relerr(dx.cpu(), dx_ref) < TOL["bf16"], (case, mode, _relerr(dx.cpu(), dx_ref))
+    assert _relerr(dw.cpu(), dw_ref) < TOL["bf16"], (case, mode, _relerr(dw.cpu(), dw_ref))
+    np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=2e-3, atol=2e-3 * float(g_.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=2e-3, atol=2e-3 * float(b_.grad.abs().max()))
 
 
 # ---- BatchNorm statistics through accumulator rows (y5m_conv_args.bn_acc + y5m_bn_act_fused, csrc/y5m_bnfuse.h): the conv
@@ -713,27 +722,6 @@ def test_conv_dgrad_fused_bn_reduction(case, dtype, src):
     r1, r2 = dt.sum((0, 2, 3)), (dt * yy).sum((0, 2, 3))
     np.testing.assert_allclose(s1.cpu().numpy(), r1.float().numpy(), rtol=2e-3, atol=2e-2)
     np.testing.assert_allclose(s2.cpu().numpy(), r2.float().numpy(), rtol=2e-3, atol=2e-2)
-
-
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("case", [CONV_CASES[2], CONV_CASES[5], CONV_CASES[7], (2, 48, 48, 50, 48, 1, 1, 0),
-                                  (2, 96, 48, 50, 48, 1, 1, 0), (2, 48, 48, 50, 96, 1, 1, 0), (2, 192, 40, 40, 192, 1, 1, 0),
-                                  CONV_CASES[0]])
-def test_conv_wgrad_non_atomic_slices(case, dtype):
-    """non-atomic split-K (one partial slice per pixel range and K-wave, NaN-filled beforehand: every element of every
-    slice must be written), summed in a fixed order by the unpack: every tile configuration incl. the K-wave ones"""
-    from yolov5m_amd import ops
-    B, Cin, H, W, Cout, k, s, p = case
-    x = _q(_rand((B, Cin, H, W), 21), dtype)
-    w = _rand((Cout, Cin, k, k), 22, -0.2, 0.2).requires_grad_(True)
-    y = F.conv2d(x, w, None, s, p)
-    dy = _q(_rand(tuple(y.shape), 23), dtype)
-    y.backward(dy)
-    got = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, dtype, slices=True).cpu()
-    assert bool(torch.isfinite(got).all())
-    assert _relerr(got, w.grad) < TOL[dtype], (case, dtype, _relerr(got, w.grad))
-    again = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, dtype, slices=True).cpu()
-    assert torch.equal(got, again)                      # fixed summation order: bit-reproducible
 
 
 def test_conv_multi_equals_separate_launches():

@@ -306,7 +306,7 @@ def test_bf16_per_layer_backward_on_engine_operands():
     step._enqueue_fb(eng)
     torch.cuda.synchronize()
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
-    checked_dx, worst = 0, {}
+    checked_dx, worst, pair_dx = 0, {}, {}
     for lay in eng.layers:
         P = m.pslices[lay.name]
         ybuf, yoff, yld = lay.y_view
@@ -340,13 +340,22 @@ def test_bf16_per_layer_backward_on_engine_operands():
         if lay.x.grad is not None and root.n_cons == 1 and lay.x.parent is None:
             wq = sd[lay.name + ".cbl.0.weight"].bfloat16().float()
             dx = torch.nn.grad.conv2d_input(xin.shape, wq, dyq, stride=st, padding=pd)
-            e["dx"] = rel(lay.x.grad.as_nchw_f32().cpu(), dx)
-            checked_dx += 1
+            if hasattr(lay, "off"):
+                # a merged C3 pair (c1 + c_skipped as ONE launch on the same input): x.grad is the SUM of the two halves
+                pend = pair_dx.pop(id(lay.x), None)
+                if pend is None:
+                    pair_dx[id(lay.x)] = dx
+                else:
+                    e["dx(pair)"] = rel(lay.x.grad.as_nchw_f32().cpu(), pend + dx)
+                    checked_dx += 1
+            else:
+                e["dx"] = rel(lay.x.grad.as_nchw_f32().cpu(), dx)
+                checked_dx += 1
         for kq, v in e.items():
             assert v <= 2e-2, (lay.name, kq, v)
             worst[kq] = max(worst.get(kq, 0.0), v)
     print("per-layer bf16 backward: worst", {k: f"{v:.2e}" for k, v in worst.items()}, "dx-checked layers", checked_dx)
-    assert checked_dx >= 20
+    assert checked_dx >= 20 and not pair_dx
 
 
 def test_bf16_train_step_vs_quantisation_aware_oracle(golden):
@@ -512,59 +521,14 @@ def test_multi_scale_plan_cache_is_bounded_by_memory(monkeypatch):
         prev = eng
 
 
-def _hunt_dump(path, m):
-    """fault hunting (tools/fault_hunt.sh): the allocator's segment / block map and every plan tensor's address range,
-    written BEFORE the replays, so that the address a "Memory access fault" names can be placed"""
-    import json
-    snap = [{"address": s["address"], "total_size": s["total_size"], "stream": s.get("stream"),
-             "blocks": [(b["size"], b["state"]) for b in s["blocks"]]} for s in torch.cuda.memory_snapshot()]
-    plans = {}
-    for key, eng in m._engines.items():
-        bufs = {}
-        def walk(prefix, obj, depth=0):
-            if torch.is_tensor(obj):
-                if obj.is_cuda:
-                    bufs[prefix] = (obj.data_ptr(), obj.numel() * obj.element_size())
-            elif isinstance(obj, (list, tuple)) and depth < 3:
-                for i, o in enumerate(obj):
-                    walk(f"{prefix}[{i}]", o, depth + 1)
-            elif hasattr(obj, "__dict__") and depth < 3 and type(obj).__name__ in ("_Layer", "Act", "_Workspace"):
-                for k, v in vars(obj).items():
-                    if k not in ("parent", "children", "producer", "x", "res", "z"):
-                        walk(f"{prefix}.{k}", v, depth + 1)
-        for k, v in vars(eng).items():
-            if k != "model":
-                walk(k, v)
-        plans[str(key)] = bufs
-    glob = {"flat_params": (m.flat_params.data_ptr(), m.flat_params.numel() * 4),
-            "flat_grads": (m.flat_grads.data_ptr(), m.flat_grads.numel() * 4)}
-    json.dump({"segments": snap, "plans": plans, "model": glob}, open(path, "w"))
-
-
-def test_multi_scale_all_sizes_twice_subprocess():
-    """runs test_multi_scale_all_sizes_twice_no_allocation_growth in a FRESH process -- the way a training run meets it.
-    In-process, behind tests that have created and destroyed a few dozen captured graphs, the replay of one of its 11
-    resident graphs faulted the GPU on some boxes ("Memory access fault ... Reason: Unknown", gone with
-    AMD_SERIALIZE_KERNEL=3, never in eager mode, never with PYTORCH_NO_CUDA_MEMORY_CACHING=1 in eager mode, never in a fresh
-    process): recorded as an open issue in DESIGN.md section 8; a fault aborts the whole pytest process, so the scenario
-    is kept out of it."""
-    import os, subprocess, sys
-    if os.environ.get("Y5M_MULTISCALE_CHILD") == "1":
-        pytest.skip("already the child")
-    env = dict(os.environ, Y5M_MULTISCALE_CHILD="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "all_sizes_twice_no_allocation_growth"],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 def test_multi_scale_all_sizes_twice_no_allocation_growth(monkeypatch):
     """the reference's multi_scale (utils/training_utils.py:11-28) draws one of the 11 sizes 320..640 step 32: cycling
     through ALL of them twice, the second pass finds every plan (and its captured graphs) resident -- same Engine objects,
     no growth of the allocator's live bytes -- and the graph-replayed run returns the losses of the eager run of the same
-    schedule (each graph replays on ITS plan's loss workspace and step() hands back ITS loss tensor)"""
-    import os
-    if os.environ.get("Y5M_MULTISCALE_CHILD") != "1":
-        pytest.skip("runs in the child process of test_multi_scale_all_sizes_twice_subprocess")
+    schedule (each graph replays on ITS plan's loss workspace and step() hands back ITS loss tensor).
+    Runs IN-PROCESS behind the rest of the suite (dozens of graphs created before it): until round 3 this scenario faulted
+    the GPU on some boxes and lived in a child process; the cause -- destroying captured graphs that hold forked branches
+    corrupts the host heap on this ROCm -- is avoided by NativeTrainStep (training_utils._keep_forever; NOTES.md)."""
     from yolov5m_amd.ultralytics_loss import ComputeLoss
     from yolov5m_amd.utils.training_utils import NativeTrainStep
     monkeypatch.delenv("Y5M_ENGINE_CACHE", raising=False)
@@ -587,8 +551,6 @@ def test_multi_scale_all_sizes_twice_no_allocation_growth(monkeypatch):
         assert len(m._engines) == 11
         torch.cuda.synchronize()
         live = torch.cuda.memory_allocated()
-        if os.environ.get("Y5M_HUNT_DUMP") and use_graph:
-            _hunt_dump(os.environ["Y5M_HUNT_DUMP"], m)
         for s, (x, t) in zip(sizes, batches):
             ls.append(float(step.step(x, t)[0]))       # graph mode: REPLAYS the graph captured on the first visit
             eng = next(reversed(m._engines.values()))

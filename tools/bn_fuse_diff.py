@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def child(path):
+def child(path, seed="rank0"):
     import torch
     from yolov5m_amd import config
     from yolov5m_amd.model import YOLOV5m
@@ -23,8 +23,8 @@ def child(path):
     m.load_state_dict(synth_state_dict(), strict=True)
     m = m.to("cuda"); m.compute_dtype = "bf16"; m.train()
     step = NativeTrainStep(m, ComputeLoss(m), nt_max=B * 8, use_graph=False)
-    x = synth_images(B, S, S, seed="img/rank0").to("cuda")
-    t = synth_labels(B, 8, seed="lab/rank0").to("cuda")
+    x = synth_images(B, S, S, seed=f"img/{seed}").to("cuda")
+    t = synth_labels(B, 8, seed=f"lab/{seed}").to("cuda")
     eng = step.load_inputs(x, t)
     step._enqueue_fb(eng)
     torch.cuda.synchronize()
@@ -51,6 +51,21 @@ def child(path):
 def main():
     tmp = os.path.join(ROOT, "gpurun_out", "bn_fuse_diff")
     os.makedirs(tmp, exist_ok=True)
+    # the same comparison on other batches first: is the sign of (fuse1 - fuse0) a property of the form or of the batch?
+    print("total gradient norm per batch (seed), Y5M_BN_FUSE=0 / 1, and a repeat of form 1 (run-to-run noise):")
+    for seed in ("rank0", "rank1", "rank2", "rank3", "rank4"):
+        g = []
+        for f in ("0", "1", "1"):
+            path = os.path.join(tmp, f"seed_{seed}_{f}.npz")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", path, seed], env=dict(os.environ, Y5M_BN_FUSE=f),
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            d = np.load(path)
+            g.append((float(d["gnorm"]), float(d["loss"][0])))
+            os.remove(path)
+        print(f"  {seed}: fuse0 {g[0][0]:9.3f}  fuse1 {g[1][0]:9.3f} ({(g[1][0] / g[0][0] - 1) * 100:+5.1f} %)  fuse1 again {g[2][0]:9.3f}   "
+              f"loss {g[0][1]:.4f} / {g[1][1]:.4f}", flush=True)
+    print()
     runs = {}
     for f in ("0", "1"):
         path = os.path.join(tmp, f"fuse{f}.npz")
@@ -95,6 +110,6 @@ def main():
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "child":
-        child(sys.argv[2])
+        child(sys.argv[2], *(sys.argv[3:4]))
     else:
         main()

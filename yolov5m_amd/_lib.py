@@ -45,7 +45,20 @@ class WgradArgs(ctypes.Structure):
     _fields_ = ([("dy", c_void_p), ("x", c_void_p), ("dwgt", c_void_p)] +
                 [(n, c_int) for n in ("B", "Hin", "Win", "ldx", "Hg", "Wg", "sy", "sx", "th", "tw", "dh0", "dhs",
                                       "dw0", "dws", "C", "N", "M", "lddy", "lddw", "ksplit", "tiles_n", "tiles_c")] +
-                [("zeros", c_void_p), ("slices_cap", c_int), ("pad_", c_int)])
+                [("zeros", c_void_p), ("reserved0", c_int), ("pad_", c_int)])
+
+
+class BwdPwSeg(ctypes.Structure):
+    """mirror of y5m_bwd_pw_seg (include/y5m.h)"""
+    _fields_ = [("c0", c_int), ("cn", c_int), ("lddz", c_int), ("pad_", c_int), ("dz", c_void_p), ("acc", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("mean", c_void_p),
+                ("invstd", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("dw", c_void_p)]
+
+
+class BwdPwArgs(ctypes.Structure):
+    """mirror of y5m_bwd_pw_args (include/y5m.h)"""
+    _fields_ = ([("y", c_void_p), ("x", c_void_p), ("wd", c_void_p), ("dx", c_void_p), ("res", c_void_p), ("M", c_int64)] +
+                [(n, c_int) for n in ("ldy", "ldx", "Kp", "lddx", "ldres", "lddw", "N", "C", "accumulate", "act", "nseg")] +
+                [("seg", BwdPwSeg * 2)])
 
 
 _zero_pages = {}
@@ -123,8 +136,8 @@ _SIGS = {
     "y5m_wgrad": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_pack_weights": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y5m_pack_weights_batched": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),
-    "y5m_wgrad_slices": (c_int, [c_void_p, c_int]),
-    "y5m_unpack_wgrad_slices": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "y5m_bwd_pw": (c_int, [c_void_p, c_int, c_void_p]),
+    "y5m_bwd_pw_eligible": (c_int, [c_void_p, c_int]),
     "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y5m_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -187,16 +187,6 @@ extern "C" int y5m_unpack_wgrad(const float* gp, int Cout, int Cin, int KH, int 
     return Y5M_OK;
 }
 
-extern "C" int y5m_unpack_wgrad_slices(const float* gp, int nslices, int64_t slice_stride, int Cout, int Cin, int KH, int KW,
-                                       int mode, int ldg, float* dst, void* stream) {
-    Y5M_REQUIRE(nslices >= 1, "nslices");
-    const int64_t n = (int64_t)Cout * Cin * KH * KW;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_blocks(n)), dim3(EW_T), 0, y5m_stream(stream), gp, nslices, slice_stride,
-                       Cout, Cin, KH, KW, mode, ldg, dst);
-    Y5M_CHECK_LAUNCH("unpack_wgrad_kernel");
-    return Y5M_OK;
-}
-
 // =================================================================================================
 // input: NCHW f32 image (B,3,H,W) -> space-to-depth NHWC (B,H/2,W/2,16): ch = (dy*2+dx)*3 + c
 // =================================================================================================

@@ -110,9 +110,6 @@ class Engine:
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
-        # Y5M_WGRAD_SERIAL (experiment): weight gradients that run INLINE on the main stream instead of on the forked one --
-        # bit 0: the 3x3 layers with both channel counts a multiple of 192, bit 1: every 3x3 layer, bit 2: every layer
-        self.serial_sel = int(os.environ.get("Y5M_WGRAD_SERIAL", "0"))
         self.ablate = set(x for x in os.environ.get("Y5M_ABLATE", "").split(",") if x)
         self.fork_mode = int(os.environ.get("Y5M_WGRAD_FORK", "1"))   # 2: fork behind the next BatchNorm backward's reduce launch
         # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
@@ -128,10 +125,13 @@ class Engine:
         # are NOT free in a conv epilogue (the pointwise kernel turns VALU-bound). Kept as a tested option.
         self.bnred = {"0": False, "all": "all"}.get(os.environ.get("Y5M_BNRED", "0"), True)
         self.merge_c3 = os.environ.get("Y5M_MERGE_C3", "1") != "0"
-        # pointwise weight gradients without atomics: one partial slice per pixel range, summed by the unpack in a
-        # fixed order (bit-reproducible). OFF by default: measured 32.6 vs 31.2 ms/step -- the slice traffic (N x C x 4
-        # bytes per pixel range, up to 2.4 MB for the 768-channel layers) costs more than the L2 atomics it replaces.
-        self.wgrad_slices = os.environ.get("Y5M_WGRAD_SLICES", "0") != "0"
+        # fused backward of the pointwise CBLs with 48 / 96 / 192 channels in and out (csrc/y5m_bwd_pw.hip): BatchNorm apply +
+        # data gradient + weight gradient in one launch after the reduce pass. Y5M_BWD_PW=0: the three-launch form
+        self.fused_pw = os.environ.get("Y5M_BWD_PW", "1") != "0"
+        # ... only for launches with at least this many pixels: the kernel owns its CU (eight waves, 130 KB of LDS at C = 192) and
+        # pays ~30 us of prologue + weight-gradient atomics per launch, so on the 40x40 layers (102 400 pixels at B = 64) the
+        # three-launch form next to the forked weight gradients is the faster one (tools/bwd_pw_bench.py, tools/ab_step.sh)
+        self.fused_pw_min_m = int(os.environ.get("Y5M_BWD_PW_MIN_M", "200000"))
         self.wgrad_direct = os.environ.get("Y5M_WGRAD_DIRECT", "1") != "0"    # 1x1 layers: atomics straight into flat_grads
         self._direct_wgrads = 0          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
         self._bwd_stack = []
@@ -323,6 +323,11 @@ class Engine:
                                    th, kw0, 2, tw, _lib.ptr(wd), wd.shape[0], wd.shape[1], 0, dt)
 
         def backward(lay=lay, P=P, need_dx=need_dx):
+            if (self.fused_pw and self.fuse_b and need_dx and lay.kk == 1 and lay.ss == 1 and lay.res is None
+                    and not lay.stem and getattr(lay, "bnred", None) is None and not self.ablate):
+                fops = self._bwd_pw_ops(lay.x, lay.y_ptr, lay.y_ld, lay.wd[0][0], [(lay, P)], lay.M, lay.cout)
+                if fops is not None:
+                    return fops
             ops = []
             z = lay.z
             dz = z.grad
@@ -495,37 +500,75 @@ class Engine:
                          bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr,
                          lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ())
 
+    def _bwd_pw_ops(self, x, y_ptr, y_ld, wd, segs, M, N):
+        """launch list entries of the fused pointwise backward (y5m_bwd_pw) of one 1x1 CBL -- or of a merged C3 pair: `segs` is
+        [(layer, flat-buffer views P)] side by side on the N output channels of the launch. Per segment the BatchNorm
+        reduction (phase 1 of y5m_bn_bwd_fused_phase) fills the layer's accumulator rows, then ONE launch forms dy in
+        registers, writes d(x) (store / accumulate / lazy residual source, same bookkeeping as the separate data gradient)
+        and adds dW straight into the flat gradient buffer. Returns None when the arguments do not qualify."""
+        from ._lib import BwdPwArgs
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        a = BwdPwArgs()
+        xg = x.grad
+        a.y, a.x, a.wd, a.dx = y_ptr, x.ptr, wd.data_ptr(), xg.ptr
+        a.M, a.ldy, a.ldx, a.Kp, a.lddx, a.lddw = M, y_ld, x.ld, wd.shape[1], xg.ld, x.C
+        a.N, a.C, a.act, a.nseg = N, x.C, ACT_SILU, len(segs)
+        c0 = 0
+        for i, (lay, P) in enumerate(segs):
+            sg, dz, bn = a.seg[i], lay.z.grad, lay.bn
+            sg.c0, sg.cn, sg.dz, sg.lddz = c0, lay.cout, dz.ptr, dz.ld
+            sg.acc = self.gw.data_ptr() + 4 * self._accb_base + 8 * lay.accb_off
+            sg.scale, sg.shift, sg.mean, sg.invstd = (bn[k].data_ptr() for k in range(4))
+            sg.dgamma, sg.dbeta, sg.dw = P["gg"].data_ptr(), P["gb"].data_ptr(), P["gw"].data_ptr()
+            c0 += lay.cout
+        if M < self.fused_pw_min_m or not L.y5m_bwd_pw_eligible(ctypes.byref(a), dt):
+            return None
+        ops = []
+        for lay, P in segs:
+            ops.extend(self._flush_lazy(lay.z))
+        acc = 1 if x.gw else 0
+        x.gw = True
+        for c in x.children:
+            c.gw = True
+        lazy, x.lazy = x.lazy, None
+        if lazy is not None:
+            assert acc == 1
+            a.res, a.ldres = lazy.ptr, lazy.ld
+        a.accumulate = acc
+        for i, (lay, P) in enumerate(segs):
+            sg = a.seg[i]
+            def reduce(lay=lay, sg=sg):
+                bn, dz = lay.bn, lay.z.grad
+                _lib.check(L.y5m_bn_bwd_fused_phase(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(),
+                                                    bn[2].data_ptr(), bn[3].data_ptr(), M, lay.cout, ACT_SILU, None, None, 0,
+                                                    None, 0, sg.acc, dt, st(), 1), "y5m_bn_bwd_fused_phase(reduce)")
+            ops.append((_kind(reduce, "bn_reduce"), ()))
+            self._grad_done.append((lay.name, P["gw"].data_ptr()))
+        def fused(a=a):
+            _lib.check(L.y5m_bwd_pw(ctypes.byref(a), dt, st()), "y5m_bwd_pw")
+        fused.bp = a
+        ops.append((_kind(fused, "bwd_pw"), ()))
+        self._direct_wgrads += 1
+        self._written(x)
+        return ops
+
     def _wgrad_ops(self, lay, wa, unpacks):
         """launch closures [wgrad, unpack...] of one weight gradient. unpacks: [(row offset, Cout, Cin, k, mode,
-        dst flat-gradient pointer)]. Pointwise layers use the non-atomic slices mode (y5m_wgrad_args.slices_cap): their
-        own buffer, no zeroing, deterministic sum; 3x3 layers accumulate with atomics into the zeroed self.gw."""
+        dst flat-gradient pointer)]. 3x3 layers accumulate with atomics into the zeroed packed buffer self.gw and are
+        unpacked into the reference layout; a 1x1 layer's packed gradient IS the reference layout."""
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
         fs = [lambda: _lib.check(L.y5m_wgrad(ctypes.byref(wa), dt, st()), "y5m_wgrad")]
-        use_slices = self.wgrad_slices and wa.th == 1 and wa.tw == 1
-        if (self.wgrad_direct and not use_slices and wa.th == 1 and wa.tw == 1 and len(unpacks) == 1 and unpacks[0][0] == 0
+        if (self.wgrad_direct and wa.th == 1 and wa.tw == 1 and len(unpacks) == 1 and unpacks[0][0] == 0
                 and unpacks[0][1] == wa.N and unpacks[0][2] == wa.lddw and unpacks[0][4] == 0):
             # a 1x1 layer's packed gradient [Cout][Cin] IS the reference layout [Cout][Cin][1][1]: accumulate straight
             # into the flat gradient buffer (zeroed at the start of the backward list), no unpack launch
             wa.dwgt = unpacks[0][5]
             self._direct_wgrads += 1
             return fs
-        if use_slices:
-            wa.slices_cap = 4096
-            ns = L.y5m_wgrad_slices(ctypes.byref(wa), dt)
-            if ns < 1:
-                raise _lib.Y5MError("y5m_wgrad_slices failed")
-            stride = wa.N * wa.lddw
-            lay.gw_slices = torch.zeros((ns * stride,), dtype=torch.float32, device=self.dev)
-            wa.dwgt, wa.slices_cap = lay.gw_slices.data_ptr(), ns
-            for (row0, cout, cin, k, mode, dst) in unpacks:
-                fs.append(lambda row0=row0, cout=cout, cin=cin, k=k, mode=mode, dst=dst: _lib.check(
-                    L.y5m_unpack_wgrad_slices(lay.gw_slices.data_ptr() + 4 * row0 * wa.lddw, ns, stride, cout, cin, k, k, mode,
-                                              wa.lddw, dst, st()), "y5m_unpack_wgrad_slices"))
-        else:
-            for (row0, cout, cin, k, mode, dst) in unpacks:
-                fs.append(lambda row0=row0, cout=cout, cin=cin, k=k, mode=mode, dst=dst: _lib.check(
-                    L.y5m_unpack_wgrad(wa.dwgt + 4 * row0 * wa.lddw, cout, cin, k, k, mode, wa.lddw, dst, st()),
-                    "y5m_unpack_wgrad"))
+        for (row0, cout, cin, k, mode, dst) in unpacks:
+            fs.append(lambda row0=row0, cout=cout, cin=cin, k=k, mode=mode, dst=dst: _lib.check(
+                L.y5m_unpack_wgrad(wa.dwgt + 4 * row0 * wa.lddw, cout, cin, k, k, mode, wa.lddw, dst, st()),
+                "y5m_unpack_wgrad"))
         return fs
 
     def _flush_lazy(self, act):
@@ -647,6 +690,10 @@ class Engine:
                            ctypes.c_void_p(wd.data_ptr() + lay.off * esz), wd.shape[0], cols, 0, dt, wd.shape[1])
 
         def backward():
+            if self.fused_pw and self.fuse_b and need_dx and not self.ablate and all(getattr(l, "bnred", None) is None for l, _ in halves):
+                fops = self._bwd_pw_ops(x, y2.data_ptr(), N2, wd, halves, M, N2)
+                if fops is not None:
+                    return fops
             ops = []
             slot = self._next_slot()
             scratch = self.scratch2[slot]
@@ -938,21 +985,14 @@ class Engine:
         """Run `fns` on the side stream, ordered after everything enqueued so far on the current stream
         (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
         hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
-        inline = not self.overlap
-        sel = self.serial_sel
         if wa is not None and self.ablate:
             # Y5M_ABLATE (TIMING ONLY, gradients WRONG): drop weight-gradient launches by class -- parameters then only see weight
             # decay, the activations / gradients flowing through the step keep their values (tools/ab_step.sh)
             taps = wa.th * wa.tw
             if ("wgrad_pw" in self.ablate and taps == 1) or ("wgrad_3x3" in self.ablate and taps > 1):
                 fns = []
-        if wa is not None and sel:
-            taps = wa.th * wa.tw
-            wide = taps > 1 and wa.C % 192 == 0 and wa.N % 192 == 0
-            inline = inline or bool((sel & 4) or ((sel & 2) and taps > 1) or ((sel & 1) and wide))
-
         def run():
-            if inline:
+            if not self.overlap:                    # (read at RUN time: a capture may switch the fork off, NativeTrainStep._capture)
                 for f in fns:
                     f()
                 return

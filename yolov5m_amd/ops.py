@@ -243,9 +243,8 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=N
     return from_nhwc(dx)
 
 
-def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0, slices=False):
-    """dy (B,Cout,Ho,Wo), x (B,Cin,H,W) -> dw (Cout,Cin,k,k): autograd of conv2d wrt its weight.
-    slices: the non-atomic mode (one partial gradient slice per pixel range, summed by the unpack)."""
+def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0):
+    """dy (B,Cout,Ho,Wo), x (B,Cin,H,W) -> dw (Cout,Cin,k,k): autograd of conv2d wrt its weight."""
     L = _lib.lib()
     dt, tdt, CH, BK = _DT[dtype]
     B, Cout, Ho, Wo = dy.shape
@@ -264,19 +263,58 @@ def conv_wgrad(dy, x, k, stride, pad, dtype="f32", ksplit=0, slices=False):
     _buf = ctypes.create_string_buffer(192)
     _lib.check(L.y5m_wgrad_kernel_name(ctypes.byref(a), dt, _buf, 192), "y5m_wgrad_kernel_name")
     LAST_WGRAD_KERNEL = _buf.value.decode()
-    if slices:
-        a.slices_cap = 4096
-        ns = L.y5m_wgrad_slices(ctypes.byref(a), dt)
-        assert ns >= 1, _lib.last_error() if hasattr(_lib, "last_error") else ns
-        gp = torch.full((ns, Cout, k * k * Cin), float("nan"), dtype=torch.float32, device=dy.device)   # no zeroing needed
-        a.dwgt, a.slices_cap = gp.data_ptr(), ns
-        _lib.check(L.y5m_wgrad(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_wgrad")
-        _lib.check(L.y5m_unpack_wgrad_slices(_lib.ptr(gp), ns, Cout * k * k * Cin, Cout, Cin, k, k, 0, k * k * Cin,
-                                             _lib.ptr(out), _lib.stream_ptr()), "y5m_unpack_wgrad_slices")
-        torch.cuda.synchronize()
-        return out
     _lib.check(L.y5m_wgrad(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_wgrad")
     _lib.check(L.y5m_unpack_wgrad(_lib.ptr(gp), Cout, Cin, k, k, 0, k * k * Cin, _lib.ptr(out), _lib.stream_ptr()),
                "y5m_unpack_wgrad")
     torch.cuda.synchronize()
     return out
+
+
+def bwd_pw(dz, y, x, w, scale, shift, mean, invstd, split=None, init=None, src=None):
+    """Fused backward of a pointwise CBL (y5m_bwd_pw; bf16, Cin == Cout in {48, 96, 192}): dz, y (B,C,H,W), x (B,C,H,W),
+    w (C,C,1,1), per-channel forward statistics scale = gamma*invstd, shift, mean, invstd (C,). The BatchNorm reduction is
+    accumulated first (y5m_bn_bwd_fused_phase, phase 1), per segment when `split` cuts the output channels in two (the merged
+    C3 pair). init: accumulate dx onto it; src: dx = src + gradient. Returns dx, dW (C,C,1,1), dgamma, dbeta."""
+    from ._lib import BwdPwArgs
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT["bf16"]
+    B, C, H, W = dz.shape
+    M = B * H * W
+    dev = dz.device
+    dzn, yn, xn = to_nhwc(dz, tdt), to_nhwc(y, tdt), to_nhwc(x, tdt)
+    dx = torch.zeros((B, H, W, C), dtype=tdt, device=dev) if init is None else to_nhwc(init, tdt)
+    srcn = to_nhwc(src, tdt) if src is not None else None
+    if src is not None:
+        dx.fill_(7.0)
+    wd = torch.zeros((_rup(C, L.y5m_conv_tile_n(C)), _rup(C, BK)), dtype=tdt, device=dev)
+    _lib.check(L.y5m_pack_weights(_lib.ptr(w.contiguous().float()), C, C, 1, 1, 1, 0, 1, 1, 0, 1, 1, _lib.ptr(wd),
+                                  wd.shape[0], wd.shape[1], 0, dt, _lib.stream_ptr()), "y5m_pack_weights")
+    segs = [(0, C)] if split is None else [(0, split), (split, C - split)]
+    slots = int(L.y5m_bn_acc_slots())
+    dw = torch.zeros((C, C), dtype=torch.float32, device=dev)
+    dgamma = torch.full((C,), float("nan"), dtype=torch.float32, device=dev)
+    dbeta = torch.full((C,), float("nan"), dtype=torch.float32, device=dev)
+    st = [t.contiguous().float() for t in (scale, shift, mean, invstd)]
+    a = BwdPwArgs()
+    a.y, a.x, a.wd, a.dx = yn.data_ptr(), xn.data_ptr(), wd.data_ptr(), dx.data_ptr()
+    a.res = srcn.data_ptr() if srcn is not None else None
+    a.M, a.ldy, a.ldx, a.Kp, a.lddx, a.ldres, a.lddw = M, C, C, wd.shape[1], C, C, C
+    a.N, a.C, a.accumulate, a.act, a.nseg = C, C, 1 if (init is not None or src is not None) else 0, ACT_SILU, len(segs)
+    keep = []
+    for i, (c0, cn) in enumerate(segs):
+        acc = torch.zeros((slots, 2, cn), dtype=torch.float64, device=dev)
+        sl = [t[c0:c0 + cn].contiguous() for t in st]
+        keep += [acc] + sl
+        _lib.check(L.y5m_bn_bwd_fused_phase(dzn.data_ptr() + 2 * c0, C, yn.data_ptr() + 2 * c0, C, _lib.ptr(sl[0]), _lib.ptr(sl[1]),
+                                            _lib.ptr(sl[2]), _lib.ptr(sl[3]), M, cn, ACT_SILU, None, None, 0, None, 0,
+                                            _lib.ptr(acc), dt, _lib.stream_ptr(), 1), "y5m_bn_bwd_fused_phase(reduce)")
+        s = a.seg[i]
+        s.c0, s.cn, s.acc = c0, cn, acc.data_ptr()
+        s.dz, s.lddz = dzn.data_ptr() + 2 * c0, C
+        s.scale, s.shift, s.mean, s.invstd = (t.data_ptr() for t in sl)
+        s.dgamma, s.dbeta = dgamma.data_ptr() + 4 * c0, dbeta.data_ptr() + 4 * c0
+        s.dw = dw.data_ptr() + 4 * c0 * C
+    assert L.y5m_bwd_pw_eligible(ctypes.byref(a), dt) == 1
+    _lib.check(L.y5m_bwd_pw(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_bwd_pw")
+    torch.cuda.synchronize()
+    return from_nhwc(dx), dw.view(C, C, 1, 1).clone(), dgamma, dbeta

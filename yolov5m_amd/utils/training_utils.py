@@ -21,6 +21,30 @@ import torch.nn as nn
 from .. import _lib, config
 
 
+# Captured graphs that contain FORKED branches (the weight gradients on the side stream) are never destroyed. Destroying
+# such a graph (torch.cuda.CUDAGraph.__del__ -> hipGraphExecDestroy / hipGraphDestroy, ROCm 7.2 + torch 2.10) corrupts the
+# host heap: the process then dies in glibc ("free(): invalid pointer", "corrupted size vs. prev_size"), segfaults inside a
+# later hipGraphLaunch, replays ANOTHER graph with damaged kernel arguments (wrong results on its first replay) or faults the
+# GPU ("Memory access fault ... Reason: Unknown") -- the round-2 "graph replay fault". tools/graph_first_replay.py
+# reproduces it within seconds (5 rounds x 15 captured plans: 3 of 3 runs clean with the graphs kept, every run dead without);
+# linear graphs (Y5M_OVERLAP=0) are destroyed cleanly (120 create / destroy cycles). So: a forked graph gets one extra
+# reference that nobody drops (it is not destroyed at interpreter shutdown either), and once Y5M_GRAPH_KEEP_MAX (64) of them
+# exist further plans are captured LINEARLY (weight gradients inline, ~5 % slower per step) so that a long multi_scale run
+# which keeps evicting and re-capturing its largest plans cannot leak without bound. NOTES.md has the hunt.
+_KEPT_GRAPHS = []
+
+
+def _keep_forever(g):
+    import ctypes as _c
+    _KEPT_GRAPHS.append(g)
+    _c.pythonapi.Py_IncRef(_c.py_object(g))
+    return g
+
+
+def _forked_capture_allowed():
+    return len(_KEPT_GRAPHS) < int(os.environ.get("Y5M_GRAPH_KEEP_MAX", "64"))
+
+
 def multi_scale(img, target_shape, max_stride):
     """reference utils/training_utils.py:11-28 (random size in [0.5x, 1x+stride) rounded to the stride,
     bilinear). Pure resampling of the input batch on whatever device it lives."""
@@ -290,13 +314,15 @@ class NativeTrainStep:
             hook.wait()
             self._optimizer()
             torch.cuda.synchronize()
+            forked, saved = eng.overlap and _forked_capture_allowed(), eng.overlap
             try:
+                eng.overlap = forked
                 gs = []
                 for i in range(len(ks)):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         seg(i)
-                    gs.append(g)
+                    gs.append(_keep_forever(g) if forked else g)
                 if self._opt_graph is None:
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, capture_error_mode="thread_local"):
@@ -309,6 +335,8 @@ class NativeTrainStep:
                 torch.cuda.synchronize()
                 self.use_graph = False
                 eng._pending.clear()
+            finally:
+                eng.overlap = saved
             return self.loss_out
         for i in range(len(ks)):
             if graphs is not None:
@@ -345,7 +373,9 @@ class NativeTrainStep:
 
     def _capture(self, eng, enqueue):
         torch.cuda.synchronize()
+        forked, saved = eng.overlap and _forked_capture_allowed(), eng.overlap
         try:
+            eng.overlap = forked
             # thread_local: a RCCL watchdog / other thread touching the HIP runtime must not abort the capture
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
@@ -355,13 +385,15 @@ class NativeTrainStep:
                 with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._optimizer()
                 self._opt_graph = g2
-            self._fb_graphs[eng.key] = (eng, g1, "whole")
+            self._fb_graphs[eng.key] = (eng, _keep_forever(g1) if forked else g1, "whole")
         except Exception as e:                           # capture is an optimisation, never a requirement
             import warnings
             warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
             torch.cuda.synchronize()
             self.use_graph = False
             eng._pending.clear()
+        finally:
+            eng.overlap = saved
 
     def _step_accumulate(self, eng):
         """micro-batch: forward/backward (+ graph replay) then gacc += grads; every `accumulate`-th call the
@@ -484,6 +516,8 @@ class NativeTrainStep:
                 convs.extend((ms * a.K / tot, a) for a in parts)
             elif d:
                 convs.append((e0.elapsed_time(e1), d[0]))
+        self.last_bwd_pw = [(e0.elapsed_time(e1), item[0].bp) for (kind, e0, e1), item in zip(tl, items)
+                            if item is not None and kind == "bwd_pw"]
         if detail != "kernels":
             return fam, convs
         # per-kernel view: (kernel instantiation name, ms, algorithmic flop) of every conv / data-gradient / weight-gradient
@@ -504,6 +538,10 @@ class NativeTrainStep:
                 elif d:
                     _lib.check(L.y5m_conv_kernel_name(ctypes.byref(d[0]), eng.dtype, buf, 192), "kernel_name")
                     kern.append((buf.value.decode(), ms, 2.0 * d[0].M * d[0].N * d[0].K))
+            elif kind == "bwd_pw":
+                a = item[0].bp          # fused pointwise backward: data gradient + weight gradient flops; HBM-bound (bench.py by_class)
+                kern.append((f"bwd_pw_kernel<{a.C},{int(bool(a.accumulate or a.res))}>", ms, 4.0 * a.M * a.N * a.C,
+                             float(a.M) * (2 * a.N + (3 if (a.accumulate or a.res) else 2) * a.C) * 2))     # + algorithmic bytes
             elif kind == "wgrad" and getattr(item[0], "wa", None) is not None:
                 wa = item[0].wa
                 _lib.check(L.y5m_wgrad_kernel_name(ctypes.byref(wa), eng.dtype, buf, 192), "kernel_name")
