@@ -199,21 +199,6 @@ typedef struct {
     int32_t tiles_m, tiles_n;   /* filled by the library                                         */
     const void* zeros;   /* >= 16 zero bytes in device memory: padding / out-of-range chunks of a    */
                          /* tile are LOADED from here, which keeps the tile loads branch-free        */
-    /* EPI_DGRAD only, optional (bn_part != NULL): the tensor being written is the gradient dz of CBL outputs
-     * z = silu(y*scale + shift) and this launch is its LAST writer, so the epilogue also emits the
-     * BatchNorm-backward reduction partials  bn_part[tile][2][Np] = (sum dt, sum dt*y),
-     * dt = dz*silu'(y*scale+shift)  -- the separate reduce pass over (dz, y) disappears
-     * (y5m_bn_bwd_from_partials). Output channels [0, bn_split) belong to producer 1 (bn_y, bn_scale,
-     * bn_shift indexed by n), channels >= bn_split to producer 2 (bn_y2 ... indexed by n - bn_split);
-     * a NULL scale pointer = no BatchNorm behind that channel range. Dense stride-1 output only. */
-    const void* bn_y;
-    const void* bn_y2;
-    const float* bn_scale;
-    const float* bn_shift;
-    const float* bn_scale2;
-    const float* bn_shift2;
-    float* bn_part;
-    int32_t bn_ldy, bn_ldy2, bn_split, bn_pad_;
     /* EPI_RAW_STATS only, optional: accumulator rows instead of partial rows (see y5m_bn_acc_slots) */
     double* bn_acc;               /* [slots][2][Np] f64, device memory, zeroed by the caller       */
 } y5m_conv_args;
@@ -354,8 +339,8 @@ size_t y5m_bn_bwd_workspace_bytes(int64_t M, int C);
 int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                      const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
                      int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype, void* stream);
-/* ... one launch at a time (phase 1 = the reduce pass, 2 = the apply pass, 3 = both): lets a caller that schedules other
- * work between them (the engine forks a weight gradient behind the reduce pass, Y5M_WGRAD_FORK=2) do so */
+/* ... one launch at a time (phase 1 = the reduce pass, 2 = the apply pass, 3 = both). Phase 1 alone is what runs ahead of
+ * y5m_bwd_pw, which forms dy itself: dgamma / dbeta / dy may then be NULL */
 int y5m_bn_bwd_fused_phase(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
                            const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
                            int accumulate_param_grads, void* dy, int lddy, double* acc, int dtype, void* stream, int phase);
@@ -363,12 +348,6 @@ int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, const float* sc
                const float* mean, const float* invstd, int64_t M, int C, int act, float* dgamma,
                float* dbeta, int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes,
                int dtype, void* stream);
-/* the same with the reduction already done by the last writer of dz (y5m_conv_args.bn_part): part is
- * [rows][2][ldpart] (sum dt, sum dt*y) for THIS layer's channels (pointer already at its first channel) */
-int y5m_bn_bwd_from_partials(const float* part, int rows, int ldpart, const void* dz, int lddz, const void* y, int ldy,
-                             const float* scale, const float* shift, const float* mean, const float* invstd, int64_t M,
-                             int C, int act, float* dgamma, float* dbeta, int accumulate_param_grads, void* dy, int lddy,
-                             void* ws, size_t ws_bytes, int dtype, void* stream);
 /* dst (+)= src on (ptr, ld) views: residual / concat gradient plumbing */
 int y5m_add(const void* src, int ldsrc, void* dst, int lddst, int64_t M, int C, int accumulate, int dtype,
             void* stream);

@@ -55,12 +55,12 @@ CONV_DEFAULTS = [
     # B, Cin, H, W, Cout, k, s -> forward (raw + statistics), data gradient
     ((64, 192, 40, 40, 192, 3, 1), "conv_halo_kernel<6,0>", "conv_halo_kernel<6,3>"),
     ((64, 384, 20, 20, 384, 3, 1), "conv_halo_kernel<6,0>", "conv_halo_kernel<6,3>"),
-    ((64, 96, 80, 80, 96, 3, 1), "conv_igemm_kernel<bf16,2,2,4,3,0,0>", "conv_igemm_kernel<bf16,2,2,4,3,0,0>"),
-    ((64, 96, 160, 160, 192, 3, 2), "conv_igemm_kernel<bf16,2,4,4,3,0,0>", None),
-    ((64, 96, 80, 80, 96, 1, 1), "conv_pw_kernel<6,3,0,0,0,0>", "conv_pw_kernel<6,3,3,0,0,0>"),
-    ((64, 48, 160, 160, 48, 3, 1), "conv_pw_kernel<3,14,0,0,0,48>", "conv_pw_kernel<3,14,3,0,0,48>"),
-    ((64, 384, 40, 40, 384, 1, 1), "conv_gemm8_kernel<0>", "conv_igemm_kernel<bf16,2,4,4,3,0,0>"),
-    ((64, 768, 20, 20, 768, 1, 1), "conv_gemm8_kernel<0>", "conv_igemm_kernel<bf16,2,4,4,3,0,0>"),
+    ((64, 96, 80, 80, 96, 3, 1), "conv_igemm_kernel<bf16,2,2,4,3,0>", "conv_igemm_kernel<bf16,2,2,4,3,0>"),
+    ((64, 96, 160, 160, 192, 3, 2), "conv_igemm_kernel<bf16,2,4,4,3,0>", None),
+    ((64, 96, 80, 80, 96, 1, 1), "conv_pw_kernel<6,3,0,0,0>", "conv_pw_kernel<6,3,3,0,0>"),
+    ((64, 48, 160, 160, 48, 3, 1), "conv_pw_kernel<3,14,0,0,48>", "conv_pw_kernel<3,14,3,0,48>"),
+    ((64, 384, 40, 40, 384, 1, 1), "conv_gemm8_kernel<0>", "conv_igemm_kernel<bf16,2,4,4,3,0>"),
+    ((64, 768, 20, 20, 768, 1, 1), "conv_gemm8_kernel<0>", "conv_igemm_kernel<bf16,2,4,4,3,0>"),
 ]
 
 WGRAD_DEFAULTS = [

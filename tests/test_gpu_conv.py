@@ -686,44 +686,6 @@ def test_bn_shared_workspace_across_widths():
                                    rtol=1e-4)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("case", [(2, 96, 16, 20, 96, 3, 96), (2, 192, 12, 12, 96, 3, 48), (2, 96, 48, 50, 96, 1, 48),
-                                  (2, 192, 48, 50, 192, 1, 96), (2, 48, 48, 50, 96, 1, 96)])
-@pytest.mark.parametrize("src", [False, True])
-def test_conv_dgrad_fused_bn_reduction(case, dtype, src):
-    """the data gradient that FINISHES dz of CBL outputs z = silu(y*scale+shift) also emits the BatchNorm
-    backward reduction (sum dt, sum dt*y), dt = dz*silu'(.), for one or two producers (channel split), tiled
-    and pointwise kernels, with and without the fused residual source"""
-    from yolov5m_amd import ops
-    B, Cout, H, W, Cin, k, C1 = case                 # dx has Cin channels: C1 from producer 1, the rest producer 2
-    p = k // 2
-    w = _q(_rand((Cout, Cin, k, k), 91, -0.2, 0.2), dtype)
-    dy = _q(_rand((B, Cout, H, W), 92), dtype)
-    x = torch.zeros((B, Cin, H, W), requires_grad=True)
-    F.conv2d(x, w, None, 1, p).backward(dy)
-    s_ = _q(_rand((B, Cin, H, W), 93), dtype) if src else None
-    dz = x.grad + (s_ if src else 0)
-    y1, sc1, sh1 = _q(_rand((B, C1, H, W), 94, -2, 2), dtype), _rand((C1,), 95, 0.5, 1.5), _rand((C1,), 96, -0.3, 0.3)
-    C2 = Cin - C1
-    second = None
-    if C2:
-        second = (_q(_rand((B, C2, H, W), 97, -2, 2), dtype), _rand((C2,), 98, 0.5, 1.5), _rand((C2,), 99, -0.3, 0.3))
-    got, s1, s2 = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, p, dtype, src=s_.to(DEV) if src else None,
-                                 bn=[(y1.to(DEV), sc1.to(DEV), sh1.to(DEV)),
-                                     tuple(t.to(DEV) for t in second) if second else None])
-    assert _relerr(got.cpu(), dz) < TOL[dtype]
-    dzq = _q(got.cpu(), dtype).double()              # the reduction is defined on dz AS STORED
-    yy = torch.cat([y1] + ([second[0]] if second else []), 1).double()
-    sc = torch.cat([sc1] + ([second[1]] if second else [])).double().view(1, -1, 1, 1)
-    sh = torch.cat([sh1] + ([second[2]] if second else [])).double().view(1, -1, 1, 1)
-    t = yy * sc + sh
-    sg = torch.sigmoid(t)
-    dt = dzq * (sg * (1 + t * (1 - sg)))
-    r1, r2 = dt.sum((0, 2, 3)), (dt * yy).sum((0, 2, 3))
-    np.testing.assert_allclose(s1.cpu().numpy(), r1.float().numpy(), rtol=2e-3, atol=2e-2)
-    np.testing.assert_allclose(s2.cpu().numpy(), r2.float().numpy(), rtol=2e-3, atol=2e-2)
-
-
 def test_conv_multi_equals_separate_launches():
     """y5m_conv_multi (the 4 parity classes of a stride-2 data gradient as ONE launch with interleaved tiles) against the
     same 4 problems launched one by one: bit-identical output (same tiles, same arithmetic). Through ops.conv_dgrad with

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-launch time of every weight-gradient launch (+ its unpack) of one eager, serialised train step (HIP events on
 the launch stream), grouped by layer shape: which layers the serial cost of the weight gradients consists of.
-usage: [Y5M_WGRAD_PC=..] python tools/wgrad_layers.py [B] [size]"""
+usage: python tools/wgrad_layers.py [B] [size]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

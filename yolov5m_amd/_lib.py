@@ -34,9 +34,6 @@ class ConvArgs(ctypes.Structure):
                 [("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("ldres", c_int),
                  ("stats", c_void_p), ("Np", c_int), ("naxs", c_int), ("nch", c_int), ("tiles_m", c_int),
                  ("tiles_n", c_int), ("zeros", c_void_p),
-                 ("bn_y", c_void_p), ("bn_y2", c_void_p), ("bn_scale", c_void_p), ("bn_shift", c_void_p),
-                 ("bn_scale2", c_void_p), ("bn_shift2", c_void_p), ("bn_part", c_void_p),
-                 ("bn_ldy", c_int), ("bn_ldy2", c_int), ("bn_split", c_int), ("bn_pad_", c_int),
                  ("bn_acc", c_void_p)])
 
 
@@ -162,9 +159,6 @@ _SIGS = {
                                  c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "y5m_bn_bwd_fused_phase": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),
-    "y5m_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                         c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "y5m_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "y5m_upsample2x": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_upsample2x_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,

@@ -9,8 +9,6 @@
 // DB = true : two LDS buffers, one barrier per K step (long K: MFMA-bound layers)
 // DB = false: one LDS buffer, two barriers per K step, half the LDS -> more resident workgroups per CU
 //             (short K, e.g. 1x1 convs with C <= 384: latency/HBM-bound, TLP hides the load latency)
-// BNR  = true : data-gradient launch that is the LAST writer of a CBL output gradient: the epilogue also emits
-//             the BatchNorm-backward reduction partials (y5m_conv_args.bn_part), see include/y5m.h
 // Channel permutation inside a wave's NF*16-channel tile: MFMA output row rho of fragment a holds local channel
 // cv_pch(a, rho). Fragments are paired so that lane (pixel, fq) holds the 8 CONSECUTIVE channels
 // p*32 + fq*8 + [0,8) of pair p = a >> 1: one 16-byte store per lane, 64 contiguous bytes per pixel and store
@@ -31,7 +29,7 @@ __device__ __forceinline__ int xcd_logical_id(int bid, int nblk) {
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 }
 
-template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR>
+template <typename T, int WM, int WN, int MF, int NF, bool DB>
 __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int lid) {
     constexpr int THREADS = WM * WN * 64, RSTEP = THREADS / 8;   // RSTEP: tile rows staged per pass (8 chunks per row)
     constexpr int CH = ElemTraits<T>::CH, BK = ElemTraits<T>::BK;
@@ -249,13 +247,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
     // dense output (no strided scatter): output pixel index == m, skip the decomposition
     const bool lin_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
                          P.Hout == P.Hg && P.Wout == P.Wg;
-    float bs1[BNR ? NF : 1][4], bs2[BNR ? NF : 1][4];          // BNR: per-lane (sum dt, sum dt*y) over the MF pixel fragments
-    if constexpr (BNR) {
-#pragma unroll
-        for (int a = 0; a < NF; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { bs1[a][r] = 0.f; bs2[a][r] = 0.f; }
-    }
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
         const int m = mb + b * 16;
@@ -324,29 +315,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
 #pragma unroll
             for (int r = 0; r < 4; ++r) fv[a][r] = v[r];
             okm |= 1u << a;
-            if constexpr (BNR) {
-                // dz as the standalone reduce pass would read it back (rounded to T), y of the producer
-                const bool second = n >= P.bn_split;
-                const float* scp = second ? P.bn_scale2 : P.bn_scale;
-                if (scp) {
-                    const int nn = second ? n - P.bn_split : n;
-                    const T* yp = second ? reinterpret_cast<const T*>(P.bn_y2) + opix * P.bn_ldy2 + nn
-                                         : reinterpret_cast<const T*>(P.bn_y) + opix * P.bn_ldy + nn;
-                    const float* shp = (second ? P.bn_shift2 : P.bn_shift) + nn;
-                    float yv[4];
-                    load4<T>(yp, yv);
-                    const float4 sc = *reinterpret_cast<const float4*>(scp + nn);
-                    const float4 sh = *reinterpret_cast<const float4*>(shp);
-                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dzr = to_f32<T>(from_f32<T>(v[r]));
-                        const float dt = dzr * silu_grad(yv[r] * scv[r] + shv[r]);
-                        bs1[a][r] += dt;
-                        bs2[a][r] += dt * yv[r];
-                    }
-                }
-            }
         }
         // stores: a complete fragment pair is 8 consecutive channels of the lane -> one 16-byte (bf16) piece
         if (P.epi != EPI_HEAD) {
@@ -374,40 +342,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
             }
         }
     }
-    if constexpr (BNR) {
-        // lanes (16 pixels) -> wave -> the WM waves of the tile, as the RAW_STATS partials
-        __syncthreads();                                       // every wave is past its last LDS tile read
-        float* red = reinterpret_cast<float*>(smem);          // [2][WM][BN]
-#pragma unroll
-        for (int a = 0; a < NF; ++a) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { bs1[a][r] += __shfl_xor(bs1[a][r], o, 64); bs2[a][r] += __shfl_xor(bs2[a][r], o, 64); }
-            }
-            if (frow == 0) {
-                const int nl = wn * NF * 16 + cv_pch<NF>(a, fq * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[(0 * WM + wm) * BN + nl + r] = bs1[a][r];
-                    red[(1 * WM + wm) * BN + nl + r] = bs2[a][r];
-                }
-            }
-        }
-        __syncthreads();
-        for (int tt = tid; tt < 2 * BN; tt += THREADS) {
-            const int which = tt / BN, nl = tt - which * BN;
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + nl];
-            if (n0 + nl < P.Np) P.bn_part[((size_t)tile_m * 2 + which) * P.Np + n0 + nl] = t;
-        }
-    }
 }
 
-template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR>
+template <typename T, int WM, int WN, int MF, int NF, bool DB>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams P) {
-    conv_igemm_body<T, WM, WN, MF, NF, DB, BNR>(P, xcd_logical_id(blockIdx.x, gridDim.x));
+    conv_igemm_body<T, WM, WN, MF, NF, DB>(P, xcd_logical_id(blockIdx.x, gridDim.x));
 }
 
 // Up to 4 problems of the same tiling in ONE launch (the parity classes of a stride-2 data gradient: same dY, same
@@ -430,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_multi_kernel(const Co
     unsigned* dst = reinterpret_cast<unsigned*>(&P);
 #pragma unroll
     for (int i = 0; i < NW; ++i) dst[i] = src[i];
-    conv_igemm_body<T, WM, WN, MF, NF, false, false>(P, lid / MP.n);
+    conv_igemm_body<T, WM, WN, MF, NF, false>(P, lid / MP.n);
 }
 
 template <typename T, int WM, int WN, int MF, int NF>
@@ -455,19 +394,19 @@ static int launch_conv_multi(ConvMulti& MP, hipStream_t st) {
     return Y5M_OK;
 }
 
-template <typename T, int WM, int WN, int MF, int NF, bool DB, bool BNR = false>
+template <typename T, int WM, int WN, int MF, int NF, bool DB>
 static int launch_conv_db(ConvParams& P, hipStream_t st) {
     constexpr int BN = WN * NF * 16, BM = WM * MF * 16;
     P.tiles_m = (P.M + BM - 1) / BM;
     P.tiles_n = (P.N + BN - 1) / BN;
     const size_t lds = (DB ? 2 : 1) * (size_t)(BM + BN) * 128;
-    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, DB, BNR>;
+    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, DB>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    Y5M_NAME_ONLY(Y5M_OK, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WM, WN, MF, NF, (int)DB, (int)BNR);
+    Y5M_NAME_ONLY(Y5M_OK, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WM, WN, MF, NF, (int)DB);
     hipLaunchKernelGGL(kern, dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(WM * WN * 64), lds, st, P);
     Y5M_CHECK_LAUNCH("conv_igemm_kernel");
     return Y5M_OK;
@@ -484,13 +423,6 @@ static int launch_conv(ConvParams& P, hipStream_t st) {
     // EVERY K, not just short ones (32.8 -> 32.3 ms/step); the double-buffered variant stays as an A/B knob
     if (g_sbuf_kt < 0) { const char* e = getenv("Y5M_CONV_SBUF_KT"); g_sbuf_kt = e ? atoi(e) : 1 << 20; }
     const int BK = sizeof(T) == 2 ? 64 : 32;
-    if constexpr (NF <= 3) {
-        // (the 192-channel tile has no register room for the 2 x NF x 4 per-lane partials: see conv_dispatch)
-        if (P.epi == EPI_DGRAD && P.bn_part) {
-            if (P.Kp / BK <= g_sbuf_kt) return launch_conv_db<T, WM, WN, MF, NF, false, true>(P, st);
-            return launch_conv_db<T, WM, WN, MF, NF, true, true>(P, st);
-        }
-    }
     if (P.Kp / BK <= g_sbuf_kt) return launch_conv_db<T, WM, WN, MF, NF, false>(P, st);
     return launch_conv_db<T, WM, WN, MF, NF, true>(P, st);
 }
@@ -540,23 +472,12 @@ static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
         if (r != 0) return r < 0 ? r : Y5M_OK;
     }
     int BN = y5m_conv_tile_n(P.N);
-    if (P.epi == EPI_DGRAD && P.bn_part && BN == 192) BN = 96;     // fused BN-backward partials: 96-channel tile
     if (dtype == Y5M_BF16) {
         if (BN == 48) return launch_conv<bf16_t, 4, 1, 2, 3>(P, st);
         if (BN == 192) {
             // Y5M_CONV_W8=1: the same 128x192 tile with 8 waves (64x48 wave tiles): twice the waves per SIMD to
             // hide barrier / LDS / load waits, 40 % more LDS reads per MFMA (A/B knob)
             if (g_w8 < 0) { const char* e = getenv("Y5M_CONV_W8"); g_w8 = e ? atoi(e) : 1; }
-            // Y5M_CONV_BM256: 256-pixel x 192-channel tile, 8 waves of 64 x 96 (the 8 waves of W8 with the wave tile of the
-            // 4-wave form: 29 % fewer LDS fragment bytes per MFMA, one workgroup per CU). Not for launches that write partial
-            // statistics rows (their callers count one row per 128 pixels). 1 = single LDS buffer, 2 = double buffer.
-            static int bm256 = -1;
-            if (bm256 < 0) { const char* e = getenv("Y5M_CONV_BM256"); bm256 = e ? atoi(e) : 0; }
-            const bool rows128 = (P.epi == EPI_RAW_STATS && P.stats && !P.bn_acc) || P.bn_part;
-            if ((bm256 & 3) && !rows128 && (P.M >= 256 * 256 || (bm256 & 4))) {       // (+4: also tiny problems -- the tests)
-                if ((bm256 & 3) == 2) return launch_conv_db<bf16_t, 4, 2, 4, 6, true>(P, st);
-                return launch_conv_db<bf16_t, 4, 2, 4, 6, false>(P, st);
-            }
             if (g_w8) return launch_conv<bf16_t, 2, 4, 4, 3>(P, st);
             return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
         }
@@ -585,13 +506,6 @@ extern "C" int y5m_conv(const y5m_conv_args* args, int dtype, void* stream) {
     Y5M_REQUIRE(P.epi != EPI_RAW_STATS || !(P.stats || P.bn_acc) || P.Np >= (P.N + BN - 1) / BN * BN, "stats stride Np too small");
     Y5M_REQUIRE(P.Np >= (P.N + BN - 1) / BN * BN, "Np (rows of the packed weights) must cover the channel tiles");
     Y5M_REQUIRE(!P.bn_acc || P.epi == EPI_RAW_STATS, "bn_acc: EPI_RAW_STATS launches only");
-    if (P.bn_part) {
-        const bool dense_out = P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 && P.Hout == P.Hg && P.Wout == P.Wg;
-        Y5M_REQUIRE(P.epi == EPI_DGRAD && dense_out, "bn_part: dense stride-1 data-gradient launches only");
-        Y5M_REQUIRE(P.bn_split % 4 == 0 && P.bn_split > 0, "bn_split must be a positive multiple of 4");
-        Y5M_REQUIRE(!P.bn_scale || (P.bn_y && P.bn_shift), "bn_y / bn_shift missing");
-        Y5M_REQUIRE(!P.bn_scale2 || (P.bn_y2 && P.bn_shift2), "bn_y2 / bn_shift2 missing");
-    }
     hipStream_t st = y5m_stream(stream);
     // The kernels address the input view with 32-bit byte offsets (buffer resources; the top bit marks
     // "out of range"), so one launch sees at most 2 GiB of input: larger batches go in slabs of whole images.
@@ -626,7 +540,7 @@ extern "C" int y5m_conv_multi(const y5m_conv_args* args, int n, int dtype, void*
     bool ok = on && n >= 2 && n <= 4 && dtype == Y5M_BF16;
     for (int i = 0; ok && i < n; ++i) {
         const y5m_conv_args& a = args[i];
-        ok = a.epi == EPI_DGRAD && !a.bn_part && a.M == args[0].M && a.N == args[0].N && a.B == args[0].B &&
+        ok = a.epi == EPI_DGRAD && a.M == args[0].M && a.N == args[0].N && a.B == args[0].B &&
              a.Hg == args[0].Hg && a.Wg == args[0].Wg && a.in == args[0].in && a.ldin == args[0].ldin &&
              a.Kp % 64 == 0 && a.Kp >= a.K && a.K == a.th * a.tw * a.Cin && a.Cin % 8 == 0 && a.ldin % 8 == 0 &&
              a.N % 4 == 0 && a.ldout % 4 == 0 && a.zeros != nullptr && a.M == a.B * a.Hg * a.Wg && a.M > 0 &&

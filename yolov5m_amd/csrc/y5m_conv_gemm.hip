@@ -350,7 +350,6 @@ static bool gemm8_geom(const ConvParams& P, int dtype, GemmArgs& G) {
     if (P.Hin != P.Hg || P.Win != P.Wg || P.Hout != P.Hg || P.Wout != P.Wg) return false;
     if (P.osy != 1 || P.osx != 1 || P.ooy != 0 || P.oox != 0) return false;
     if (P.epi != EPI_RAW_STATS && P.epi != EPI_AFFINE_ACT && P.epi != EPI_DGRAD) return false;
-    if (P.bn_part) return false;
     if (P.Cin < 384 || P.Cin % 64 != 0 || P.K != P.Cin || P.Kp < P.Cin || P.ldin % 8 != 0) return false;
     if (P.N % 192 != 0 || P.Np < P.N || P.N > 4096) return false;                  // (N <= 4096: the LDS statistics table)
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return false;      // 16-byte output pieces
@@ -384,11 +383,7 @@ static int launch_gemm8(const ConvParams& P, const GemmArgs& G, hipStream_t st) 
         attr = true;
     }
     g_gemm8_cus = y5m_persistent_cus();
-    // Y5M_CONV_GEMM8_NP=1 (experiment): data-gradient launches with ONE work item per workgroup (grid = items), so that the
-    // workgroups are short-lived and interleave with the forked weight gradient's blocks
-    static int np = -1;
-    if (np < 0) { const char* e = getenv("Y5M_CONV_GEMM8_NP"); np = e ? atoi(e) : 0; }
-    const int grid = (np && EPI == EPI_DGRAD) ? G.total : (G.total < g_gemm8_cus ? G.total : g_gemm8_cus);
+    const int grid = G.total < g_gemm8_cus ? G.total : g_gemm8_cus;
     Y5M_NAME_ONLY(Y5M_OK, "conv_gemm8_kernel<%d>", EPI);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(GM_THREADS), lds, st, P, G);
     Y5M_CHECK_LAUNCH("conv_gemm8_kernel");

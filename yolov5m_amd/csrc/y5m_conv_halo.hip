@@ -515,9 +515,10 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
 
 // ------------------------------------------------------------------------------------------------------------------
 int y5m_conv_gemm8_stat_rows(const ConvParams& P, int dtype);      // y5m_conv_gemm.hip
-static int g_halo = -1;            // Y5M_CONV_HALO: 0 = tiled kernel everywhere (A/B runs), 1 (default) = 192-channel tiles only, 2 = also the
-                                   // 96-channel tile (N = 96: 24 MFMAs per wave and phase do not cover the other group's R
-                                   // phase -- 490-580 TFLOP/s against 520-670 for the tiled kernel on 96 -> 96 @ 80x80)
+static int g_halo = -1;            // Y5M_CONV_HALO: 0 = tiled kernel everywhere (A/B runs), 1 (default) = the 192-channel tile
+                                   // (a 96-channel tile, NF = 3, was built and measured in round 2: 24 MFMAs per wave and phase
+                                   // do not cover the other group's R phase -- 490-580 TFLOP/s against 520-670 for the tiled
+                                   // kernel on 96 -> 96 @ 80x80; removed in round 3, NOTES.md)
 static int g_halo_cus = 0;
 
 static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
@@ -529,12 +530,10 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     if (P.Hin != P.Hg || P.Win != P.Wg || P.Hout != P.Hg || P.Wout != P.Wg) return false;
     if (P.osy != 1 || P.osx != 1 || P.ooy != 0 || P.oox != 0) return false;
     if (P.epi != EPI_RAW_STATS && P.epi != EPI_AFFINE_ACT && P.epi != EPI_DGRAD) return false;
-    if (P.bn_part) return false;
     if (P.bn_acc && !P.stats) return false;                 // accumulator rows: this kernel stages its tiles' sums in stats rows
     if (P.Cin < 64 || P.Cin % 32 != 0 || P.ldin % 8 != 0) return false;
-    if (P.N % 96 != 0) return false;
-    BN = (P.N % 192 == 0 && P.Cin % 64 == 0) ? 192 : 96;
-    if (BN == 96 && g_halo < 2) return false;
+    if (P.N % 192 != 0 || P.Cin % 64 != 0) return false;
+    BN = 192;
     if (P.Np < (P.N + BN - 1) / BN * BN) return false;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return false;      // 16-byte output pieces
     if (P.res && P.ldres % 4 != 0) return false;
@@ -615,12 +614,7 @@ int y5m_conv_halo_try(const ConvParams& P, int dtype, hipStream_t st) {
     int BN;
     if (!halo_geom(P, dtype, G, BN)) return 0;
     int r;
-    if (BN == 192) {
-        r = P.epi == EPI_RAW_STATS ? launch_halo<6, EPI_RAW_STATS>(P, G, st)
-          : P.epi == EPI_AFFINE_ACT ? launch_halo<6, EPI_AFFINE_ACT>(P, G, st) : launch_halo<6, EPI_DGRAD>(P, G, st);
-    } else {
-        r = P.epi == EPI_RAW_STATS ? launch_halo<3, EPI_RAW_STATS>(P, G, st)
-          : P.epi == EPI_AFFINE_ACT ? launch_halo<3, EPI_AFFINE_ACT>(P, G, st) : launch_halo<3, EPI_DGRAD>(P, G, st);
-    }
+    r = P.epi == EPI_RAW_STATS ? launch_halo<6, EPI_RAW_STATS>(P, G, st)
+      : P.epi == EPI_AFFINE_ACT ? launch_halo<6, EPI_AFFINE_ACT>(P, G, st) : launch_halo<6, EPI_DGRAD>(P, G, st);
     return r == Y5M_OK ? 1 : r;
 }

@@ -31,8 +31,6 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // prefetch index is clamped instead of guarded): with every load / store on the straight path the compiler
 // can count them, so the wait for the prefetched x fragments is a vmcnt(#stores issued since) and the
 // output stores of group g drain under the MFMAs of group g+1 instead of being waited for.
-// BNR: EPI_DGRAD launch that also emits the BatchNorm-backward reduction partials of the gradient it
-// finishes (y5m_conv_args.bn_part): the per-lane sums live in the same registers the forward statistics use.
 // Local channel (within the workgroup's chunk) of accumulator register 0 of fragment `a` for the lanes with
 // fq = lane >> 4 (the same function places the weight rows: A row rho of fragment a holds channel
 // pw_lch(a, rho >> 2) + (rho & 3)).
@@ -40,8 +38,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 //     pair p = a >> 1, so ONE store instruction writes 64 contiguous bytes per pixel (16 B per lane, the four
 //     lanes of a pixel adjacent). With the lane-contiguous layout below the L2 received 21 B per write request
 //     (PMC: 7.4 M write requests for 157 MB, 72 % of all its requests) and the stores cost 40 % of the kernel.
-//   !PERM: a lane holds 4*NCF consecutive channels (48 B runs, 48 B apart): kept for the BNR epilogue, whose
-//     per-lane producer selection needs a lane's channels on one side of bn_split.
+//   (!PERM: a lane holds 4*NCF consecutive channels -- 48 B runs, 48 B apart; the layout PERM replaced.)
 template <int NCF, bool PERM>
 __device__ __forceinline__ constexpr int pw_lch(int a, int fq) {
     if (!PERM) return fq * (4 * NCF) + a * 4;
@@ -54,11 +51,11 @@ __device__ __forceinline__ constexpr int pw_lch(int a, int fq) {
 // of an x fragment comes from its own tap (k = s*32 + fq*8 -> tap k >> 4 = 2s + (fq >> 1), channel half (fq & 1) * 8)
 // with its own image-border test (out-of-image taps read the zero page). The tiled kernel spends 3 K steps per
 // 128-pixel tile here and runs at 40 % of the HBM rate this layer is bound by (839 MB in 0.43 ms).
-template <int NCF, int KS, int EPI, bool OLD, bool BNR, int TAPC = 0>
+template <int NCF, int KS, int EPI, bool OLD, int TAPC = 0>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams P, const int nchunks, const int nstreams,
                                                                const int ngroups, const int stat_rows) {
     constexpr int NC = NCF * 16;
-    constexpr bool PERM = !BNR;
+    constexpr bool PERM = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NCF][KS][64 lanes] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -91,20 +88,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
             sc[j] = P.scale[c]; sh[j] = P.shift[c];
         }
     }
-    constexpr bool SUMS = EPI == EPI_RAW_STATS || BNR;
+    constexpr bool SUMS = EPI == EPI_RAW_STATS;
     float ssum[SUMS ? 4 * NCF : 1], ssq[SUMS ? 4 * NCF : 1];
-    // BNR: this lane's 4*NCF channels belong to ONE producer (chunks never straddle bn_split, a multiple of 48)
-    const bool bn_second = BNR && cbase >= P.bn_split;
-    const int bn_c = bn_second ? cbase - P.bn_split : cbase;
-    const float* bn_scp = BNR ? (bn_second ? P.bn_scale2 : P.bn_scale) : nullptr;
-    const bf16_t* bn_yb = reinterpret_cast<const bf16_t*>(bn_second ? P.bn_y2 : P.bn_y);
-    const int bn_ld = bn_second ? P.bn_ldy2 : P.bn_ldy;
-    float bsc[BNR ? 4 * NCF : 1], bsh[BNR ? 4 * NCF : 1];
-    if constexpr (BNR) {
-        const float* shp = bn_second ? P.bn_shift2 : P.bn_shift;
-#pragma unroll
-        for (int j = 0; j < 4 * NCF; ++j) { bsc[j] = bn_scp ? bn_scp[bn_c + j] : 0.f; bsh[j] = bn_scp ? shp[bn_c + j] : 0.f; }
-    }
     if constexpr (SUMS) {
 #pragma unroll
         for (int j = 0; j < 4 * NCF; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
@@ -210,21 +195,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
             q.x = f32x2_to_bf16x2(v[0], v[1]);
             q.y = f32x2_to_bf16x2(v[2], v[3]);
             qa[a] = q;
-            if constexpr (BNR) {
-                if (bn_scp) {
-                    const u32x2 yq = *reinterpret_cast<const u32x2*>(bn_yb + p * bn_ld + bn_c + a * 4);
-                    const float yv[4] = {__uint_as_float(yq.x << 16), __uint_as_float(yq.x & 0xffff0000u),
-                                         __uint_as_float(yq.y << 16), __uint_as_float(yq.y & 0xffff0000u)};
-                    const float dz[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
-                                         __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};   // as stored
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dt = dz[r] * silu_grad(yv[r] * bsc[a * 4 + r] + bsh[a * 4 + r]);
-                        ssum[a * 4 + r] += dt;
-                        ssq[a * 4 + r] += dt * yv[r];
-                    }
-                }
-            }
         }
         // stores: one 16-byte piece per fragment pair (PERM: the 4 lanes of a pixel write 64 contiguous bytes)
 #pragma unroll
@@ -259,8 +229,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
     }
 
     if constexpr (SUMS) {
-        float* const rows_out = BNR ? P.bn_part : P.stats;
-        const bool fuse = !BNR && P.bn_acc != nullptr;           // accumulator rows instead of partial rows (y5m_bnfuse.h)
+        float* const rows_out = P.stats;
+        const bool fuse = P.bn_acc != nullptr;           // accumulator rows instead of partial rows (y5m_bnfuse.h)
         if (rows_out || fuse) {
             // lanes -> wave (16 pixel lanes share a channel set), waves -> workgroup (through LDS, behind the
             // weights), one stats row per WORKGROUP: row `sblock`; rows sblock + k*gridDim-per-chunk are zero
@@ -296,7 +266,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const ConvParams
 static int g_pw = -1;          // Y5M_CONV_PW=0 routes every layer through the tiled kernel (A/B runs)
 static int g_pw_occ = -1;      // Y5M_CONV_PW_OCC: workgroups per CU of the persistent grid
 
-template <int NCF, int KS, int EPI, bool OLD, bool BNR = false, int TAPC = 0>
+template <int NCF, int KS, int EPI, bool OLD, int TAPC = 0>
 static int launch_pw(const ConvParams& P, hipStream_t st) {
     constexpr int NC = NCF * 16;
     if (g_pw_occ < 0) { const char* e = getenv("Y5M_CONV_PW_OCC"); g_pw_occ = e ? atoi(e) : 2; }      // (re-swept with the weight gradient forked after the data gradient: 2 beats 4 by ~0.15 ms/step)
@@ -311,17 +281,17 @@ static int launch_pw(const ConvParams& P, hipStream_t st) {
     if (sblocks < 8) sblocks = 8;
     const int need = (ngroups + 3) / 4;
     if (sblocks > (need + 7) / 8 * 8) sblocks = (need + 7) / 8 * 8;
-    if (((EPI == EPI_RAW_STATS && P.stats && !P.bn_acc) || BNR) && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
+    if (EPI == EPI_RAW_STATS && P.stats && !P.bn_acc && sblocks > stat_rows) sblocks = stat_rows / 8 * 8;
     if (sblocks < 8) return 0;                                       // tiny problem: leave it to the tiled kernel
     const int nstreams = sblocks * 4;
-    const size_t lds = (size_t)NCF * KS * 64 * 16 + ((EPI == EPI_RAW_STATS || BNR) ? 4 * 2 * NC * sizeof(float) : 0);
-    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, BNR, TAPC>;
+    const size_t lds = (size_t)NCF * KS * 64 * 16 + (EPI == EPI_RAW_STATS ? 4 * 2 * NC * sizeof(float) : 0);
+    auto kern = conv_pw_kernel<NCF, KS, EPI, OLD, TAPC>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    Y5M_NAME_ONLY(1, "conv_pw_kernel<%d,%d,%d,%d,%d,%d>", NCF, KS, EPI, (int)OLD, (int)BNR, TAPC);
+    Y5M_NAME_ONLY(1, "conv_pw_kernel<%d,%d,%d,%d,%d>", NCF, KS, EPI, (int)OLD, TAPC);
     hipLaunchKernelGGL(kern, dim3((unsigned)(sblocks * nchunks)), dim3(PW_THREADS), lds, st, P, nchunks, nstreams, ngroups, stat_rows);
     Y5M_CHECK_LAUNCH("conv_pw_kernel");
     return 1;
@@ -332,8 +302,6 @@ static int launch_pw_epi(const ConvParams& P, hipStream_t st) {
     if (P.epi == EPI_RAW_STATS) return launch_pw<NCF, KS, EPI_RAW_STATS, false>(P, st);
     if (P.epi == EPI_AFFINE_ACT)
         return P.res ? launch_pw<NCF, KS, EPI_AFFINE_ACT, true>(P, st) : launch_pw<NCF, KS, EPI_AFFINE_ACT, false>(P, st);
-    if (P.bn_part)
-        return P.accumulate ? launch_pw<NCF, KS, EPI_DGRAD, true, true>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false, true>(P, st);
     return P.accumulate ? launch_pw<NCF, KS, EPI_DGRAD, true>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false>(P, st);
 }
 
@@ -341,8 +309,7 @@ static int launch_pw_epi(const ConvParams& P, hipStream_t st) {
 // caller then uses the tiled kernel), < 0 on error.
 static bool pw_eligible(const ConvParams& P, int dtype);
 
-// 1 when y5m_conv would run this launch on the pointwise streaming kernel (memory-bound: epilogue VALU work
-// such as the fused BatchNorm-backward partials is free there), 0 for the tiled implicit-GEMM kernel.
+// 1 when y5m_conv would run this launch on the pointwise streaming kernel, 0 for the tiled implicit-GEMM kernel.
 extern "C" int y5m_conv_is_pointwise(const y5m_conv_args* args, int dtype) {
     ConvParams P;
     memcpy(&P, args, sizeof(P));
@@ -359,7 +326,7 @@ static int tap_kind(const ConvParams& P, int dtype) {
     if (on48 < 0) { const char* e = getenv("Y5M_CONV_PW_TAP48"); on48 = e ? atoi(e) : 3; }   // measured: bit 0 -0.13, bit 1 -0.08, bit 2 +-0 ms/step
     if (dtype != Y5M_BF16 || P.th != 3 || P.tw != 3 || P.K != 9 * P.Cin || P.ldin % 8 != 0) return 0;
     const bool dense_out = P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 && P.Hout == P.Hg && P.Wout == P.Wg;
-    if (!dense_out || P.M % 16 != 0 || P.bn_part || P.epi == EPI_HEAD) return 0;
+    if (!dense_out || P.M % 16 != 0 || P.epi == EPI_HEAD) return 0;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return 0;
     if (P.res && P.ldres % 4 != 0) return 0;
     if (P.epi == EPI_RAW_STATS && (!(P.stats || P.bn_acc) || (P.M + CV_BM - 1) / CV_BM < 8)) return 0;
@@ -377,10 +344,10 @@ static int tap_kind(const ConvParams& P, int dtype) {
 
 template <int NCF, int KS, int TAPC>
 static int launch_tap_epi(const ConvParams& P, hipStream_t st) {
-    if (P.epi == EPI_RAW_STATS) return launch_pw<NCF, KS, EPI_RAW_STATS, false, false, TAPC>(P, st);
+    if (P.epi == EPI_RAW_STATS) return launch_pw<NCF, KS, EPI_RAW_STATS, false, TAPC>(P, st);
     if (P.epi == EPI_AFFINE_ACT)
-        return P.res ? launch_pw<NCF, KS, EPI_AFFINE_ACT, true, false, TAPC>(P, st) : launch_pw<NCF, KS, EPI_AFFINE_ACT, false, false, TAPC>(P, st);
-    return (P.accumulate || P.res) ? launch_pw<NCF, KS, EPI_DGRAD, true, false, TAPC>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false, false, TAPC>(P, st);
+        return P.res ? launch_pw<NCF, KS, EPI_AFFINE_ACT, true, TAPC>(P, st) : launch_pw<NCF, KS, EPI_AFFINE_ACT, false, TAPC>(P, st);
+    return (P.accumulate || P.res) ? launch_pw<NCF, KS, EPI_DGRAD, true, TAPC>(P, st) : launch_pw<NCF, KS, EPI_DGRAD, false, TAPC>(P, st);
 }
 
 int y5m_conv_pw_try(const ConvParams& P, int dtype, hipStream_t st) {
@@ -415,13 +382,12 @@ static bool pw_eligible(const ConvParams& P, int dtype) {
     if (P.Cin % 16 != 0 || P.Cin > 192 || P.Cin <= 32 || P.N % 48 != 0 || P.M % 16 != 0) return 0;
     if (P.res && P.ldres % 4 != 0) return 0;
     if (P.ldout % 8 != 0 || (reinterpret_cast<uintptr_t>(P.out) & 15) != 0) return 0;      // 16-byte output pieces
-    if (P.bn_part && (P.bn_split % 48 != 0 || P.bn_ldy % 4 != 0 || (P.bn_y2 && P.bn_ldy2 % 4 != 0))) return 0;
     const int KS = (P.Cin + 31) / 32;
     if (KS * 32 > P.Kp) return 0;
     if (KS != 2 && KS != 3 && KS != 6) return 0;
     // (tiny problems stay on the tiled kernel: launch_pw needs >= 8 stream blocks)
     const int ngroups = (P.M + 15) / 16, stat_rows = (P.M + CV_BM - 1) / CV_BM;
     if ((ngroups + 3) / 4 < 1) return 0;
-    if (((P.epi == EPI_RAW_STATS && P.stats) || P.bn_part) && stat_rows < 8) return 0;
+    if (P.epi == EPI_RAW_STATS && P.stats && stat_rows < 8) return 0;
     return 1;
 }

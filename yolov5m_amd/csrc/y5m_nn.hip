@@ -875,32 +875,6 @@ extern "C" int y5m_bn_bwd_fused(const void* dz, int lddz, const void* y, int ldy
                                   accumulate_param_grads, dy, lddy, acc, dtype, stream, 3);
 }
 
-extern "C" int y5m_bn_bwd_from_partials(const float* part, int rows, int ldpart, const void* dz, int lddz, const void* y,
-                                        int ldy, const float* scale, const float* shift, const float* mean,
-                                        const float* invstd, int64_t M, int C, int act, float* dgamma, float* dbeta,
-                                        int accumulate_param_grads, void* dy, int lddy, void* ws, size_t ws_bytes, int dtype,
-                                        void* stream) {
-    Y5M_REQUIRE(C % 8 == 0 && C <= 16384, "C");
-    if (ws_bytes < y5m_bn_bwd_workspace_bytes(M, C)) { y5m_set_error("bn_bwd ws too small"); return Y5M_EWS; }
-    char* w = reinterpret_cast<char*>(ws);
-    unsigned* ctr = reinterpret_cast<unsigned*>(w);
-    w += BN_CTR_BYTES + y5m_align((size_t)BNR_MAX_GX * 2 * C * 4);
-    float* cB = reinterpret_cast<float*>(w), *cD = cB + C;
-    w += y5m_align((size_t)2 * C * 4);
-    float* stage = reinterpret_cast<float*>(w);
-    hipStream_t st = y5m_stream(stream);
-    BnFinArgs F{};
-    BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads, 0};
-    hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)bn_splits(rows), (unsigned)((C + 63) / 64)), dim3(1024), 0,
-                       st, part, rows, ldpart, C, stage, ctr, F, G);
-    Y5M_CHECK_LAUNCH("bn_reduce_finalize_kernel");
-    const EwGeom ga = ew_geom(M, C / 8, 4096);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(ga.gx, (unsigned)ga.groups), dim3(256), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, cB, cD, (const float*)nullptr,
-                                         (T*)dy, lddy, M, C, ga.CG, ga.RP, act, BnFusedBwd{});)
-    Y5M_CHECK_LAUNCH("bn_bwd_apply_kernel");
-    return Y5M_OK;
-}
 
 // =================================================================================================
 // gradient plumbing: dst (+)= src over (ptr, ld) views

@@ -111,19 +111,12 @@ class Engine:
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
         self.ablate = set(x for x in os.environ.get("Y5M_ABLATE", "").split(",") if x)
-        self.fork_mode = int(os.environ.get("Y5M_WGRAD_FORK", "1"))   # 2: fork behind the next BatchNorm backward's reduce launch
         # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
         # so it runs ahead of the side stream instead of ping-ponging with it (each cross-stream wait costs
         # ~10-15 us of dependency latency inside a hipGraph); 0.63 GB per slot at B=64 / 640^2; with the weight gradient forked after the data gradient 3 slots measure
         # 0.35 ms/step better than 2 (and than 4)
         self.nslots = max(2, int(os.environ.get("Y5M_SLOTS", "3")))
         self.lazy_residual = os.environ.get("Y5M_LAZY_RES", "1") != "0"
-        # BN-backward reduction fused into the gradient's last data-gradient launch (y5m_conv_args.bn_part):
-        # "1" pointwise launches only, "all" every eligible launch, "0" off. OFF by default -- measured at
-        # B=64 / 640^2: "all" (67 of 79 layers) conv +3.0 ms vs BN backward -2.0 ms; pointwise-only conv +1.4 vs
-        # BN -1.1: the silu' + two FMAs + y read per element that a purely HBM-bound reduce pass does for free
-        # are NOT free in a conv epilogue (the pointwise kernel turns VALU-bound). Kept as a tested option.
-        self.bnred = {"0": False, "all": "all"}.get(os.environ.get("Y5M_BNRED", "0"), True)
         self.merge_c3 = os.environ.get("Y5M_MERGE_C3", "1") != "0"
         # fused backward of the pointwise CBLs with 48 / 96 / 192 channels in and out (csrc/y5m_bwd_pw.hip): BatchNorm apply +
         # data gradient + weight gradient in one launch after the reduce pass. Y5M_BWD_PW=0: the three-launch form
@@ -324,7 +317,7 @@ class Engine:
 
         def backward(lay=lay, P=P, need_dx=need_dx):
             if (self.fused_pw and self.fuse_b and need_dx and lay.kk == 1 and lay.ss == 1 and lay.res is None
-                    and not lay.stem and getattr(lay, "bnred", None) is None and not self.ablate):
+                    and not lay.stem and not self.ablate):
                 fops = self._bwd_pw_ops(lay.x, lay.y_ptr, lay.y_ld, lay.wd[0][0], [(lay, P)], lay.M, lay.cout)
                 if fops is not None:
                     return fops
@@ -401,8 +394,6 @@ class Engine:
                         assert acc == 1
                         a.res, a.ldres = lazy.ptr, lazy.ld
                     a.Np = wd.shape[0]
-                    if lay.ss == 1:
-                        self._bnred_plan(lay.x, a)
                     lay.dgrad_args.append(a)
                 if len(lay.dgrad_args) > 1:
                     # stride 2: the parity classes read the same dy -- one launch with their tiles interleaved (y5m_conv_multi)
@@ -436,61 +427,12 @@ class Engine:
     def _written(self, act):
         self._root(act).n_written += 1
 
-    def _bnred_plan(self, target, a):
-        """`a` (ConvArgs of a dense stride-1 data gradient writing ALL of target.grad) is about to be emitted.
-        If it is the LAST writer of that gradient and the tensor is the output of one or two CBLs, let its
-        epilogue emit their BatchNorm-backward reduction partials: the producers then skip their reduce pass
-        (include/y5m.h: y5m_conv_args.bn_part). Returns nothing; marks producer.bnred."""
-        if not self.bnred or not self._is_last_writer(target):
-            return
-        # only where the extra epilogue work (silu', two FMAs, a read of y per element) is free: the HBM-bound
-        # pointwise kernel. On the MFMA-bound tiled kernel it cost more than the reduce pass it replaces
-        # (measured: conv +3.0 ms vs BN backward -2.0 ms with every eligible layer fused).
-        if self.bnred != "all" and not self.L.y5m_conv_is_pointwise(ctypes.byref(a), self.dtype):
-            return
-        segs = sorted(target.children, key=lambda c: c.c0) if target.children else [target]
-        if len(segs) > 2 or segs[0].c0 != 0 or sum(c.C for c in segs) != target.C:
-            return
-        if len(segs) == 2 and segs[1].c0 != segs[0].C:
-            return
-        prods = [c.producer for c in segs]
-        if all(p is None for p in prods) or segs[0].C % 48 != 0:
-            return
-        rows = (target.M + 127) // 128
-        part = torch.zeros((rows, 2, a.Np), dtype=torch.float32, device=self.dev)
-        a.bn_part, a.bn_split = part.data_ptr(), segs[0].C
-        for i, (seg, p) in enumerate(zip(segs, prods)):
-            if p is None:
-                continue
-            if i == 0:
-                a.bn_y, a.bn_ldy, a.bn_scale, a.bn_shift = p.y_ptr, p.y_ld, p.bn[0].data_ptr(), p.bn[1].data_ptr()
-            else:
-                a.bn_y2, a.bn_ldy2, a.bn_scale2, a.bn_shift2 = p.y_ptr, p.y_ld, p.bn[0].data_ptr(), p.bn[1].data_ptr()
-            p.bnred = (part, part.data_ptr() + 4 * seg.c0, a.Np, rows)
-
     def _bn_backward_op(self, lay, P, dz, scratch_ptr, lddy):
-        """the BatchNorm + SiLU backward launch list entry of one CBL: from the partials its gradient's last
-        writer left (lay.bnred) when there are any, else the standalone reduce + finalise + apply"""
+        """the BatchNorm + SiLU backward launch list entry of one CBL: reduce + apply (dy into the scratch slot)"""
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
         bn = lay.bn
-        red = getattr(lay, "bnred", None)
-        if red is not None:
-            _keep, pptr, ldp, rows = red
-            return (lambda: _lib.check(
-                L.y5m_bn_bwd_from_partials(pptr, rows, ldp, dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(),
-                                           bn[1].data_ptr(), bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU,
-                                           _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr, lddy, _lib.ptr(self.bnws),
-                                           self._bnws_bytes, dt, st()), "y5m_bn_bwd_from_partials"), ())
         if self.fuse_b:
             accp = self.gw.data_ptr() + 4 * self._accb_base + 8 * lay.accb_off       # zeroed with gw at the start of the pass
-            if self.fork_mode == 2:
-                # the two launches as two list entries: the weight gradient of the layer above is forked between them
-                def phase(ph):
-                    return lambda: _lib.check(
-                        L.y5m_bn_bwd_fused_phase(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(),
-                                                 bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]),
-                                                 _lib.ptr(P["gb"]), 0, scratch_ptr, lddy, accp, dt, st(), ph), "y5m_bn_bwd_fused_phase")
-                return [(_kind(phase(1), "bn_reduce"), ()), (phase(2), ())]
             return (lambda: _lib.check(
                 L.y5m_bn_bwd_fused(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                                    bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0,
@@ -690,7 +632,7 @@ class Engine:
                            ctypes.c_void_p(wd.data_ptr() + lay.off * esz), wd.shape[0], cols, 0, dt, wd.shape[1])
 
         def backward():
-            if self.fused_pw and self.fuse_b and need_dx and not self.ablate and all(getattr(l, "bnred", None) is None for l, _ in halves):
+            if self.fused_pw and self.fuse_b and need_dx and not self.ablate:
                 fops = self._bwd_pw_ops(x, y2.data_ptr(), N2, wd, halves, M, N2)
                 if fops is not None:
                     return fops
@@ -728,7 +670,6 @@ class Engine:
                 g.Cin, g.K, g.Kp, g.N, g.M = N2, N2, wd.shape[1], K, M
                 g.Hout, g.Wout, g.ldout, g.osy, g.osx, g.ooy, g.oox = x.H, x.W, x.grad.ld, 1, 1, 0, 0
                 g.epi, g.act, g.accumulate, g.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
-                self._bnred_plan(x, g)
                 self._written(x)
                 ops.append((_kind(lambda g=g: _lib.check(L.y5m_conv(ctypes.byref(g), dt, st()), "y5m_conv(pair dgrad)"),
                                   "conv_igemm"), ()))
@@ -954,16 +895,6 @@ class Engine:
                         while j < len(self.bwd) and getattr(self.bwd[j][0], "kind", None) == "conv_igemm":
                             out.append(self.bwd[j])
                             j += 1
-                        if self.fork_mode == 2:
-                            # Y5M_WGRAD_FORK=2: ... and behind the NEXT BatchNorm backward's reduce launch (it starts on an
-                            # empty chip; the weight gradient then runs next to the apply launch and what follows). Never
-                            # across another weight gradient or a join (the dy ring's order is kept).
-                            k = j
-                            while k < len(self.bwd) and getattr(self.bwd[k][0], "kind", None) not in ("wgrad", "join", "bn_reduce"):
-                                k += 1
-                            if k < len(self.bwd) and getattr(self.bwd[k][0], "kind", None) == "bn_reduce":
-                                out.extend(self.bwd[j:k + 1])
-                                j = k + 1
                         out.append(op)
                         i = j
                     else:

@@ -172,13 +172,10 @@ def conv_forward_bn_fused(x, w, stride, pad, gamma, beta, running_mean, running_
     return from_nhwc(out), from_nhwc(z), res[0], res[1], res[2], res[3], rm, rv
 
 
-def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=None):
+def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None):
     """dy (B,Cout,Ho,Wo), w (Cout,Cin,k,k) -> dx (B,Cin,H,W): autograd of conv2d wrt its input.
     init (B,Cin,H,W): accumulate the gradient onto it (the engine's fan-out accumulation).
-    src  (B,Cin,H,W): dx = src + gradient with src read from its OWN tensor (the fused residual gradient).
-    bn   [(y (B,C1,H,W), scale (C1,), shift (C1,)), (y2, scale2, shift2) or None]: dx is the gradient of
-         z = silu(y*scale+shift) for channels [0,C1) (and of the second producer for the rest); also returns the
-         BatchNorm-backward reduction (sum dt, sum dt*y) per channel of dx, emitted by the conv epilogue."""
+    src  (B,Cin,H,W): dx = src + gradient with src read from its OWN tensor (the fused residual gradient)."""
     L = _lib.lib()
     dt, tdt, CH, BK = _DT[dtype]
     B, Cout, Ho, Wo = dy.shape
@@ -219,27 +216,8 @@ def conv_dgrad(dy, w, in_hw, stride, pad, dtype="f32", init=None, src=None, bn=N
         a.accumulate = 0 if (init is None and src is None) else 1
         if srcn is not None:
             a.res, a.ldres = srcn.data_ptr(), Cin
-        if bn is not None:
-            assert stride == 1
-            rows = (a.M + 127) // 128
-            part = torch.full((rows, 2, a.Np), 7.0, dtype=torch.float32, device=dy.device)
-            keep = []
-            (y1, sc1, sh1), second = bn
-            y1n, sc1, sh1 = to_nhwc(y1, tdt), sc1.float().contiguous(), sh1.float().contiguous()
-            keep += [y1n, sc1, sh1]
-            a.bn_y, a.bn_ldy, a.bn_scale, a.bn_shift = y1n.data_ptr(), y1.shape[1], sc1.data_ptr(), sh1.data_ptr()
-            a.bn_split = y1.shape[1]
-            if second is not None:
-                y2, sc2, sh2 = second
-                y2n, sc2, sh2 = to_nhwc(y2, tdt), sc2.float().contiguous(), sh2.float().contiguous()
-                keep += [y2n, sc2, sh2]
-                a.bn_y2, a.bn_ldy2, a.bn_scale2, a.bn_shift2 = y2n.data_ptr(), y2.shape[1], sc2.data_ptr(), sh2.data_ptr()
-            a.bn_part = part.data_ptr()
         _conv(a, dt, "y5m_conv(dgrad)")
         torch.cuda.synchronize()
-    if bn is not None:
-        ps = part.sum(0)
-        return from_nhwc(dx), ps[0, :Cin], ps[1, :Cin]
     return from_nhwc(dx)
 
 
