@@ -24,18 +24,19 @@ for f in glob.glob("gpurun_out/pmc_step/g*/**/*counter_collection.csv", recursiv
 print("# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-graph ... (tools/pmc_step.sh)")
 print("# B=64 @ 640x640 bf16 train step, eager launches on the step's own two streams; counters SUMMED over every launch of the")
 print("# kernel in the run (3 steps); FETCH_SIZE / WRITE_SIZE in KiB as reported (gfx950: x2 on FETCH_SIZE for wide reads).")
-print("# derived: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES) [the 4 SIMDs of a CU share one SQ]; ")
-print("#          stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES, issue = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES;")
-print("#          lds_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES / 4 ... all ratios of sums, so launch counts cancel.")
+print("# derived (ratios of sums, launch counts cancel). GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launches = GUI / 8.")
+print("#   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI / 8); lds_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x GUI / 8)")
+print("#   issue / stall / parked = SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY / SQ_WAIT_ANY over SQ_WAVE_CYCLES; lds_stall = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES")
+print("#   l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS); HBM MB/launch = (FETCH_SIZE x 2048 + WRITE_SIZE x 1024) / launches; L2 req MB/launch = TCC_REQ x 128 / launches")
 keep = ("conv_", "wgrad", "bwd_pw", "bn_bwd", "bn_act")
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
     if not any(s in k for s in keep):
         continue
     n = max(calls[k].values())
     wc = max(d.get("SQ_WAVE_CYCLES", 0), 1.0)
-    bc = max(d.get("SQ_BUSY_CYCLES", 0), 1.0)
+    cyc = max(d.get("GRBM_GUI_ACTIVE", 0), 1.0) / 8
     print(f"\n{k}   launches {n}")
-    print(f"   mfma_busy {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * bc):.3f}  issue {d.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}  "
+    print(f"   mfma_busy {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024 * cyc):.3f}  lds_busy {d.get('SQ_LDS_IDX_ACTIVE', 0) / (256 * cyc):.3f}  issue {d.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}  "
           f"stall {d.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}  parked {d.get('SQ_WAIT_ANY', 0) / wc:.3f}  "
           f"lds_stall {d.get('SQ_WAIT_INST_LDS', 0) / wc:.3f}  "
           f"l2_hit {d.get('TCC_HIT_sum', 0) / max(d.get('TCC_HIT_sum', 0) + d.get('TCC_MISS_sum', 0), 1):.3f}  "
