@@ -191,6 +191,12 @@ def lib():
             raise Y5MError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                            f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH)
+        if os.environ.get("Y5M_LIB"):
+            # another build of the library (timing / instrumentation builds under build/exp/): say so, loudly -- a stray
+            # Y5M_LIB in the environment must not go unnoticed in a training run
+            import sys
+            sys.stderr.write(f"[yolov5m_amd] WARNING: Y5M_LIB is set: using {LIB_PATH} instead of the in-tree liby5m.so "
+                             "(experiment build; not for training)\n")
         for name, (res, args) in list(_SIGS.items()):
             fn = getattr(L, name)
             fn.restype = res

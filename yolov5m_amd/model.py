@@ -242,7 +242,11 @@ class YOLOV5m(nn.Module):
             budget = gb * 2**30 if gb > 0 else 0.6 * torch.cuda.get_device_properties(dev).total_memory
             per_px = max((e.nbytes / max(e.key[0] * e.key[1] * e.key[2], 1) for e in self._engines.values()
                           if e.key[3:] == key[3:]), default=0.0)
-            need = per_px * B * H * W                     # estimate from a resident plan of the same dtype / mode
+            if per_px == 0.0:
+                # the first plan of this dtype / mode: estimate from ANY resident plan (an eval plan holds about a third of a
+                # training plan per pixel, an f32 one twice a bf16 one: the larger figure errs towards evicting)
+                per_px = max((e.nbytes / max(e.key[0] * e.key[1] * e.key[2], 1) for e in self._engines.values()), default=0.0)
+            need = per_px * B * H * W                     # estimate from a resident plan (of the same dtype / mode when there is one)
             while self._engines and (len(self._engines) >= cap or
                                      sum(e.nbytes for e in self._engines.values()) + need > budget):
                 self._engines.pop(next(iter(self._engines))).release()
@@ -251,7 +255,16 @@ class YOLOV5m(nn.Module):
             import gc
             gc.collect()
             m0 = torch.cuda.memory_allocated(dev)
-            eng = Engine(self, B, H, W, dtype=dt, training=self.training)
+            try:
+                eng = Engine(self, B, H, W, dtype=dt, training=self.training)
+            except torch.OutOfMemoryError:
+                # the estimate was too small (or there was nothing to estimate from): drop EVERY resident plan and retry once
+                while self._engines:
+                    self._engines.pop(next(iter(self._engines))).release()
+                gc.collect()
+                torch.cuda.empty_cache()
+                m0 = torch.cuda.memory_allocated(dev)
+                eng = Engine(self, B, H, W, dtype=dt, training=self.training)
             eng.key = key
             eng.nbytes = max(torch.cuda.memory_allocated(dev) - m0, 0)
             while self._engines and sum(e.nbytes for e in self._engines.values()) + eng.nbytes > budget:

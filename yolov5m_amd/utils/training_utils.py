@@ -172,7 +172,10 @@ class NativeTrainStep:
         # multi_scale came back to a size. It is dropped with the plan (Engine.release).
         ws = getattr(eng, "_loss_ws", None)
         if ws is None or ws.key != (B, eng.naxs, tuple(shapes), self.nt_max):
+            m0 = torch.cuda.memory_allocated(outs[0].device)
             ws = eng._loss_ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
+            # (the plan cache budgets by Engine.nbytes: the workspace belongs to the plan)
+            eng.nbytes = getattr(eng, "nbytes", 0) + max(torch.cuda.memory_allocated(outs[0].device) - m0, 0)
         grads = eng.head_grad_buffers()
         sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
         if sparse and getattr(ws, "owner_ptrs", None) is None:
