@@ -354,6 +354,70 @@ def test_bf16_per_layer_backward_on_engine_operands():
     assert checked_dx >= 20 and not pair_dx
 
 
+def test_submodule_forward_matches_torch():
+    """`model.backbone[i](x)` / `model.head(xs)` (reference model.py:26, :49, :90, :106, :165): every sub-module's own forward
+    runs natively, forward only, in f32 parity mode -- against the same layers in plain torch on the CPU (conv2d +
+    batch_norm + SiLU, cat / add / max_pool2d), eval mode (running statistics) and train mode (batch statistics + running
+    update). Covers the stem's 3 input channels, stride 2, a backbone C3 (residual bottlenecks), a neck C3 (no residual),
+    SPPF and the three head convs (255 channels + bias + the view / permute)."""
+    import torch.nn.functional as F
+    m = _model("f32")
+    ref = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+
+    def cbl(name, x, train):
+        w = ref[f"{name}.cbl.0.weight"]
+        k = w.shape[-1]
+        s, p = {"backbone.0": (2, 2), "backbone.1": (2, 1), "backbone.3": (2, 1), "neck.4": (2, 1)}.get(name, (1, k // 2))
+        y = F.conv2d(x, w, None, s, p)
+        z = F.batch_norm(y, ref[f"{name}.cbl.1.running_mean"].clone(), ref[f"{name}.cbl.1.running_var"].clone(),
+                         ref[f"{name}.cbl.1.weight"], ref[f"{name}.cbl.1.bias"], train, 0.03, 1e-3)
+        return F.silu(z)
+
+    def c3(name, x, depth, backbone, train):
+        t = cbl(f"{name}.c1", x, train)
+        for d in range(depth):
+            if backbone:
+                t = cbl(f"{name}.seq.{d}.c2", cbl(f"{name}.seq.{d}.c1", t, train), train) + t
+            else:
+                t = cbl(f"{name}.seq.{d}.1", cbl(f"{name}.seq.{d}.0", t, train), train)
+        return cbl(f"{name}.c_out", torch.cat([t, cbl(f"{name}.c_skipped", x, train)], 1), train)
+
+    def close(a, b, tol=1e-4):
+        assert a.shape == b.shape
+        assert float((a.cpu() - b).abs().max()) <= tol * float(b.abs().max()), float((a.cpu() - b).abs().max() / b.abs().max())
+
+    for train in (False, True):
+        m.train(train)
+        x = synth_images(2, 64, 96, seed="sub")                       # (2,3,64,96)
+        close(m.backbone[0](x.to(DEV)), cbl("backbone.0", x, train))
+        x1 = _rand_like((2, 48, 32, 48), 7)
+        close(m.backbone[1](x1.to(DEV)), cbl("backbone.1", x1, train))
+        x2 = _rand_like((2, 96, 16, 24), 8)
+        close(m.backbone[2](x2.to(DEV)), c3("backbone.2", x2, 2, True, train), 3e-4 if train else 1e-4)
+        x3 = _rand_like((2, 768, 4, 6), 9)
+        t = cbl("backbone.9.c1", x3, train)
+        p1 = F.max_pool2d(t, 5, 1, 2); p2 = F.max_pool2d(p1, 5, 1, 2); p3 = F.max_pool2d(p2, 5, 1, 2)
+        close(m.backbone[9](x3.to(DEV)), cbl("backbone.9.c_out", torch.cat([t, p1, p2, p3], 1), train), 3e-4 if train else 1e-4)
+        x4 = _rand_like((2, 384, 8, 12), 10)
+        close(m.neck[3](x4.to(DEV)), c3("neck.3", x4, 2, False, train), 3e-4 if train else 1e-4)
+        if train:                                                      # the running statistics moved as torch's did
+            bn = m.backbone[1].cbl[1]
+            y = F.conv2d(x1, ref["backbone.1.cbl.0.weight"], None, 2, 1)
+            rm = 0.97 * ref["backbone.1.cbl.1.running_mean"] + 0.03 * y.mean((0, 2, 3))
+            np.testing.assert_allclose(bn.running_mean.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
+    m.eval()
+    xs = [_rand_like((2, 192, 8, 12), 11), _rand_like((2, 384, 4, 6), 12), _rand_like((2, 768, 2, 3), 13)]
+    got = m.head([t.to(DEV) for t in xs])
+    for i in range(3):
+        y = F.conv2d(xs[i], ref[f"head.out_convs.{i}.weight"], ref[f"head.out_convs.{i}.bias"])
+        close(got[i], y.view(2, 3, 85, y.shape[2], y.shape[3]).permute(0, 1, 3, 4, 2).contiguous())
+
+
+def _rand_like(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * 2 - 1
+
+
 def test_bf16_train_step_vs_quantisation_aware_oracle(golden):
     """the benchmarked arithmetic (bf16 storage, f32 accumulation, train mode) at B = 16 @ 320x320 against
     oracle/model_ref.forward(quant=True): the SAME network with values rounded to bf16 exactly where the HIP path stores

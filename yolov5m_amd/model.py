@@ -1,11 +1,16 @@
 """YOLOV5m -- same constructor / attributes / state_dict surface as the reference model.py:178-239,
 executed by the native gfx950 engine (yolov5m_amd/engine.py) instead of ATen.
 
-The sub-modules (CBL, Bottleneck, C3, SPPF, HEADS) exist to carry parameters under the reference's
+The sub-modules (CBL, Bottleneck, C3, SPPF, HEADS) carry the parameters under the reference's
 names (481 state_dict keys) with PyTorch's default initialisation; their tensors are
 re-pointed into ONE flat f32 parameter buffer (and one flat gradient buffer) the first time the model
 runs on the GPU, which is what the fused optimizer and the RCCL gradient all-reduce operate on.
-Only YOLOV5m.forward executes: it is a single autograd Function around the native forward/backward.
+YOLOV5m.forward is a single autograd Function around the native forward / backward plan (the hot path).
+The sub-modules' own forward() (reference model.py:26, :49, :90, :106, :165 -- `model.backbone[i](x)`) also executes,
+FORWARD ONLY: every CBL is a native conv (+ batch statistics) + BatchNorm + SiLU launch sequence through the op-level
+C-ABI wrappers (yolov5m_amd/ops.py: NCHW in / out with a layout conversion per call, `compute_dtype` "f32" unless set), the
+glue between CBLs (residual add, channel concat) is torch tensor arithmetic on the GPU, the SPPF pools are the native kernel.
+The result carries no autograd graph: gradients exist only through the whole model.
 """
 import os
 
@@ -25,8 +30,34 @@ class CBL(nn.Module):
         bn = nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
         self.cbl = nn.Sequential(conv, bn, nn.SiLU(inplace=True))
 
+    compute_dtype = "f32"        # sub-module execution: "f32" (parity) or "bf16"; per instance or on the class
+
     def forward(self, x):
-        raise _lib.Y5MError("sub-modules are parameter containers; run the whole YOLOV5m (native engine)")
+        """reference model.py:26-28, forward only (no autograd graph): train mode uses batch statistics and updates the
+        running ones (momentum 0.03, eps 1e-3), eval mode the folded running statistics"""
+        from . import ops
+        _lib.require_cuda(x)
+        conv, bn = self.cbl[0], self.cbl[1]
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        ch = 8 if self.compute_dtype == "bf16" else 4
+        x = x.detach().float()
+        w = conv.weight.detach().float()
+        if x.shape[1] % ch:                                   # the stem's 3 input channels: zero channels up to a 16-byte piece
+            padc = ch - x.shape[1] % ch
+            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, padc))
+        with torch.no_grad():
+            if self.training:
+                _y, z, _sc, _sh, _mean, _invstd, rm, rv = ops.conv_forward_bn_fused(
+                    x, w, s, p, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                    self.compute_dtype)
+                bn.running_mean.copy_(rm)
+                bn.running_var.copy_(rv)
+                bn.num_batches_tracked += 1
+                return z
+            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+            return ops.conv_forward(x, w, s, p, self.compute_dtype, scale=scale, shift=shift, act=True)
 
 
 class Bottleneck(nn.Module):
@@ -37,6 +68,10 @@ class Bottleneck(nn.Module):
         c_ = int(width_multiple * in_channels)
         self.c1 = CBL(in_channels, c_, kernel_size=1, stride=1, padding=0)
         self.c2 = CBL(c_, out_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        """reference model.py:49-50"""
+        return self.c2(self.c1(x)) + x.float()
 
 
 class C3(nn.Module):
@@ -53,6 +88,10 @@ class C3(nn.Module):
             self.seq = nn.Sequential(*[nn.Sequential(CBL(c_, c_, 1, 1, 0), CBL(c_, c_, 3, 1, 1)) for _ in range(depth)])
         self.c_out = CBL(c_ * 2, out_channels, kernel_size=1, stride=1, padding=0)
 
+    def forward(self, x):
+        """reference model.py:90-92"""
+        return self.c_out(torch.cat([self.seq(self.c1(x)), self.c_skipped(x)], dim=1))
+
 
 class SPPF(nn.Module):
     """reference model.py:96-112"""
@@ -63,6 +102,13 @@ class SPPF(nn.Module):
         self.c1 = CBL(in_channels, c_, 1, 1, 0)
         self.pool = nn.MaxPool2d(kernel_size=5, stride=1, padding=2)
         self.c_out = CBL(c_ * 4, out_channels, 1, 1, 0)
+
+    def forward(self, x):
+        """reference model.py:106-112: the three cascaded 5x5 max-pools are ONE native launch (y5m_sppf_pool)"""
+        from . import ops
+        x = self.c1(x)
+        p1, p2, p3 = ops.sppf_pool(x, self.c1.compute_dtype)
+        return self.c_out(torch.cat([x, p1, p2, p3], dim=1))
 
 
 class HEADS(nn.Module):
@@ -80,6 +126,26 @@ class HEADS(nn.Module):
         self.out_convs = nn.ModuleList()
         for in_channels in ch:
             self.out_convs += [nn.Conv2d(in_channels=in_channels, out_channels=(5 + self.nc) * self.naxs, kernel_size=1)]
+
+    compute_dtype = "f32"
+
+    def forward(self, x):
+        """reference model.py:165-175: per scale a 1x1 conv with bias, viewed as (B, naxs, ny, nx, 5 + nc); forward only"""
+        from . import ops
+        out = []
+        for i in range(self.nl):
+            conv = self.out_convs[i]
+            xi = x[i].detach().float()
+            _lib.require_cuda(xi)
+            with torch.no_grad():
+                ncout = conv.weight.shape[0]
+                padn = (-ncout) % 4                                            # 255 -> 256 output channels: 16-byte rows
+                w = torch.nn.functional.pad(conv.weight.detach().float(), (0, 0, 0, 0, 0, 0, 0, padn))
+                b = torch.nn.functional.pad(conv.bias.detach().float(), (0, padn))
+                y = ops.conv_forward(xi, w, 1, 0, self.compute_dtype, scale=torch.ones_like(b), shift=b, act=False)[:, :ncout]
+            bs, _, ny, nx = y.shape
+            out.append(y.view(bs, self.naxs, 5 + self.nc, ny, nx).permute(0, 1, 3, 4, 2).contiguous())
+        return out
 
 
 class _ModelFn(torch.autograd.Function):

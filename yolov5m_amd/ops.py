@@ -296,3 +296,19 @@ def bwd_pw(dz, y, x, w, scale, shift, mean, invstd, split=None, init=None, src=N
     _lib.check(L.y5m_bwd_pw(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_bwd_pw")
     torch.cuda.synchronize()
     return from_nhwc(dx), dw.view(C, C, 1, 1).clone(), dgamma, dbeta
+
+
+def sppf_pool(x, dtype="f32"):
+    """x (B,C,H,W) -> the three cascaded MaxPool2d(5,1,2) outputs (reference model.py:108-110) in one native launch"""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    _lib.require_cuda(x)
+    B, C, H, W = x.shape
+    xn = to_nhwc(x, tdt)
+    outs = [torch.zeros_like(xn) for _ in range(3)]
+    wsb = L.y5m_sppf_pool_workspace_bytes(B, H, W, C)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=x.device)
+    _lib.check(L.y5m_sppf_pool(xn.data_ptr(), C, B, H, W, C, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                               _lib.ptr(ws), wsb, dt, _lib.stream_ptr()), "y5m_sppf_pool")
+    torch.cuda.synchronize()
+    return tuple(from_nhwc(o) for o in outs)
