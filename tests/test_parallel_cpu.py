@@ -87,3 +87,17 @@ def test_buckets_cover_flat_buffer_in_backward_order():
     assert all(lo in offs or lo == 0 for lo, _ in bk)             # cut only at layer-unit starts
     assert sum(hi - lo for lo, hi in bk) == n
     assert 4 <= len(bk) <= 12
+
+
+def test_bench_gpus_n_refuses_without_devices():
+    """`python bench.py --gpus 2` where fewer than 2 GPUs are visible (here: none) must fail loudly -- exit code != 0, the
+    reason on stderr, no JSON line -- instead of reporting a 2-GPU number from one rank (the round-2 behaviour)"""
+    import subprocess, sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two or more GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "Y5M_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
