@@ -335,8 +335,8 @@ __global__ __launch_bounds__(GM_THREADS) void conv_gemm8_kernel(const ConvParams
 // workgroup holds its CU (226 VGPRs x 8 waves) for the whole launch, and the weight-gradient blocks of the forked stream
 // (100+ us each) and these workgroups then wait for each other per CU instead of interleaving block by block as the tiled
 // kernel's short-lived workgroups do -- the same reason the halo kernel's data gradient takes 108 us in the step against
-// 73 us for its forward. Launching the data gradients with one work item per workgroup (Y5M_CONV_GEMM8_NP=1: short-lived
-// workgroups) recovers a third of the loss (27.71 vs 27.78 vs 27.57 ms). Hence forward only.
+// 73 us for its forward. Launching the data gradients with one work item per workgroup (short-lived workgroups, a knob
+// since removed) recovered a third of the loss (27.71 vs 27.78 vs 27.57 ms). Hence forward only.
 static int g_gemm8 = -1;
 static int g_gemm8_cus = 0;
 static int g_gemm8_min_tiles = -1; // Y5M_CONV_GEMM8_MIN: fewer work items than this stay on the tiled kernel

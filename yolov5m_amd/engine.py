@@ -342,8 +342,8 @@ class Engine:
                     lay.res.lazy = dz
                 else:
                     ops.extend(self._flush_lazy(lay.res))
-                    ops.append((lambda rg=rg, dz=dz, acc=acc: _lib.check(
-                        L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), ()))
+                    ops.append((_kind(lambda rg=rg, dz=dz, acc=acc: _lib.check(
+                        L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), "add"), ()))
             # BN + SiLU backward -> dy (scratch), dgamma, dbeta
             ops.extend(_as_list(self._bn_backward_op(lay, P, dz, scratch.data_ptr(), lay.cout)))
             # weight gradient (packed f32, atomics into the zeroed gw buffer)
@@ -433,14 +433,14 @@ class Engine:
         bn = lay.bn
         if self.fuse_b:
             accp = self.gw.data_ptr() + 4 * self._accb_base + 8 * lay.accb_off       # zeroed with gw at the start of the pass
-            return (lambda: _lib.check(
+            return (_kind(lambda: _lib.check(
                 L.y5m_bn_bwd_fused(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                                    bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0,
-                                   scratch_ptr, lddy, accp, dt, st()), "y5m_bn_bwd_fused"), ())
-        return (lambda: _lib.check(
+                                   scratch_ptr, lddy, accp, dt, st()), "y5m_bn_bwd_fused"), "bn_bwd(reduce + apply)"), ())
+        return (_kind(lambda: _lib.check(
             L.y5m_bn_bwd(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                          bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr,
-                         lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), ())
+                         lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), "bn_bwd(reduce + apply)"), ())
 
     def _bwd_pw_ops(self, x, y_ptr, y_ld, wd, segs, M, N):
         """launch list entries of the fused pointwise backward (y5m_bwd_pw) of one 1x1 CBL -- or of a merged C3 pair: `segs` is
@@ -521,16 +521,23 @@ class Engine:
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
         src, g = act.lazy, act.grad
         act.lazy = None
-        return [(lambda: _lib.check(L.y5m_add(src.ptr, src.ld, g.ptr, g.ld, act.B * act.H * act.W, act.C, 0, dt, st()),
-                                    "y5m_add(lazy)"), ())]
+        return [(_kind(lambda: _lib.check(L.y5m_add(src.ptr, src.ld, g.ptr, g.ld, act.B * act.H * act.W, act.C, 0, dt, st()),
+                                          "y5m_add(lazy)"), "add"), ())]
 
     def _c3(self, name, x, cout, width, depth, backbone, dest=None):
         """reference model.py:54-92"""
         c_ = int(width * x.C)
-        cat = self._new_act(x.B, x.H, x.W, 2 * c_)
-        s0, s1 = cat.slice(0, c_), cat.slice(c_, c_)
         merged = self.training and self.merge_c3
-        t = self._cbl_pair(f"{name}.c1", f"{name}.c_skipped", x, c_, s1) if merged else self._cbl(f"{name}.c1", x, c_, 1, 1, 0)
+        if self.merge_c3 and not self.training:
+            # eval: [seq output | c_skipped output | c1 output] side by side in ONE buffer; c_skipped + c1 are one folded conv
+            # that writes channels [c_, 3 c_), c_out reads channels [0, 2 c_) -- x is read once, one launch less per C3
+            wide = self._new_act(x.B, x.H, x.W, 3 * c_)
+            cat, s0 = wide.slice(0, 2 * c_), wide.slice(0, c_)
+            t = self._cbl_pair_eval(f"{name}.c_skipped", f"{name}.c1", x, c_, wide.slice(c_, 2 * c_), wide.slice(2 * c_, c_))
+        else:
+            cat = self._new_act(x.B, x.H, x.W, 2 * c_)
+            s0, s1 = cat.slice(0, c_), cat.slice(c_, c_)
+            t = self._cbl_pair(f"{name}.c1", f"{name}.c_skipped", x, c_, s1) if merged else self._cbl(f"{name}.c1", x, c_, 1, 1, 0)
         for d in range(depth):
             last = d == depth - 1
             if backbone:
@@ -539,9 +546,39 @@ class Engine:
             else:
                 u = self._cbl(f"{name}.seq.{d}.0", t, c_, 1, 1, 0)
                 t = self._cbl(f"{name}.seq.{d}.1", u, c_, 3, 1, 1, dest=s0 if last else None)
-        if not merged:
+        if not merged and (self.training or not self.merge_c3):
             self._cbl(f"{name}.c_skipped", x, c_, 1, 1, 0, dest=s1)
         return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0, dest=dest)
+
+    def _cbl_pair_eval(self, nameA, nameB, x, cout, dest2, destB):
+        """eval mode: two 1x1 CBLs on the same input (C3's c_skipped and c1, reference model.py:77, :69) as ONE conv with
+        N = 2*cout and the folded (scale, shift) of both side by side; `dest2` is the 2*cout-channel view both halves land
+        in, `destB` its second half (returned: the input of the bottleneck chain)."""
+        L, dt = self.L, self.dtype
+        esz = 2 if self.tdt == torch.bfloat16 else 4
+        N2, K = 2 * cout, x.C
+        Kp = _rup(K, self.BK)
+        Np2 = _rup(N2, L.y5m_conv_tile_n(N2))
+        wf = torch.zeros((Np2, Kp), dtype=self.tdt, device=self.dev)
+        bn2 = torch.zeros((2, N2), dtype=torch.float32, device=self.dev)      # scale, shift of both halves
+        lay = _Layer()
+        lay.name, lay.x, lay.res, lay.stem = nameA + "+" + nameB.rsplit(".", 1)[-1], x, None, False
+        lay.cin_real, lay.cout, lay.k, lay.s, lay.p = x.C, N2, 1, 1, 0
+        lay.kk, lay.ss, lay.pp, lay.M, lay.Ho, lay.Wo = 1, 1, 0, x.M, x.H, x.W
+        lay.K, lay.Kp, lay.Np, lay.z, lay.wf, lay.bn = K, Kp, Np2, dest2, wf, bn2
+        for name, off in ((nameA, 0), (nameB, cout)):
+            P = self.model.pslices[name]
+            rows = cout if off == 0 else Np2 - cout          # the second job also zero-fills the row padding
+            self._call(self.pack, L.y5m_pack_weights, _lib.ptr(P["w"]), cout, x.C, 1, 1, 0, 0, 1, 1, 0, 1, 1,
+                       ctypes.c_void_p(wf.data_ptr() + off * Kp * esz), rows, Kp, 0, dt)
+            self._fold_jobs.append((P["g"].data_ptr(), P["b"].data_ptr(), P["rm"].data_ptr(), P["rv"].data_ptr(),
+                                    bn2[0].data_ptr() + 4 * off, bn2[1].data_ptr() + 4 * off, cout))
+        a = self._conv_args(x, wf, dest2.ptr, x.H, x.W, 1, 1, 0, N2, dest2.ld, EPI_AFFINE_ACT, Kp,
+                            act=ACT_SILU, scale=bn2[0].data_ptr(), shift=bn2[1].data_ptr())
+        lay.fwd_args = a
+        self._run_conv(self.fwd, a)
+        self.layers.append(lay)
+        return destB
 
     def _cbl_pair(self, nameA, nameB, x, cout, destB):
         """C3's two 1x1 CBLs on the SAME input (reference model.py:69 c1 and :77 c_skipped) as ONE GEMM with
@@ -685,9 +722,9 @@ class Engine:
         sl = [cat.slice(i * c_, c_) for i in range(4)]
         self._cbl(f"{name}.c1", x, c_, 1, 1, 0, dest=sl[0])
         sppfws = torch.zeros((L.y5m_sppf_pool_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
-        self.fwd.append((lambda: _lib.check(L.y5m_sppf_pool(sl[0].ptr, cat.ld, x.B, x.H, x.W, c_, sl[1].ptr, sl[2].ptr,
-                                                           sl[3].ptr, _lib.ptr(sppfws), sppfws.numel(), dt, st()),
-                                            "y5m_sppf_pool"), ()))
+        self.fwd.append((_kind(lambda: _lib.check(L.y5m_sppf_pool(sl[0].ptr, cat.ld, x.B, x.H, x.W, c_, sl[1].ptr, sl[2].ptr,
+                                                                 sl[3].ptr, _lib.ptr(sppfws), sppfws.numel(), dt, st()),
+                                                  "y5m_sppf_pool"), "pool"), ()))
         if self.training:
             poolws = torch.zeros((L.y5m_maxpool5_bwd_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
             for _ in range(3):
@@ -700,10 +737,10 @@ class Engine:
                 g = [s.grad for s in sl]
                 # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)   (cascade of model.py:108-110)
                 for lvl in (2, 1, 0):
-                    ops.append((lambda lvl=lvl: _lib.check(
+                    ops.append((_kind(lambda lvl=lvl: _lib.check(
                         L.y5m_maxpool5_bwd(sl[lvl].ptr, cat.ld, g[lvl + 1].ptr, g[lvl + 1].ld, x.B, x.H, x.W, c_,
                                            g[lvl].ptr, g[lvl].ld, 1, _lib.ptr(poolws), poolws.numel(), dt, st()),
-                        "y5m_maxpool5_bwd"), ()))
+                        "y5m_maxpool5_bwd"), "pool"), ()))
                 return ops
             self._bwd_stack.append(backward)
         return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0)
@@ -711,8 +748,8 @@ class Engine:
     def _upsample_into(self, x, dst):
         """reference model.py:225 (nearest x2), written straight into its concat slice"""
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
-        self.fwd.append((lambda: _lib.check(L.y5m_upsample2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, dst.ptr, dst.ld, dt, st()),
-                                            "y5m_upsample2x"), ()))
+        self.fwd.append((_kind(lambda: _lib.check(L.y5m_upsample2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, dst.ptr, dst.ld, dt, st()),
+                                                  "y5m_upsample2x"), "upsample"), ()))
         if self.training:
             self._consume(x)
 
@@ -721,9 +758,9 @@ class Engine:
                 self._written(x)
                 acc = 1 if x.gw else 0
                 x.gw = True
-                return pre + [(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
-                                                                 x.grad.ptr, x.grad.ld, acc, dt, st()),
-                                            "y5m_upsample2x_bwd"), ())]
+                return pre + [(_kind(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
+                                                                       x.grad.ptr, x.grad.ld, acc, dt, st()),
+                                                  "y5m_upsample2x_bwd"), "upsample"), ())]
             self._bwd_stack.append(backward)
 
     def _head(self, i, x):
@@ -817,8 +854,8 @@ class Engine:
         # input: NCHW f32 images -> space-to-depth NHWC (no gradient)
         self.x_in = torch.zeros((B, 3, H, W), dtype=torch.float32, device=self.dev)
         s2d = self._new_act(B, H // 2, W // 2, 16, need_grad=False)
-        self.fwd.append((lambda: _lib.check(L.y5m_s2d_input(_lib.ptr(self.x_in), B, H, W, s2d.ptr, dt, _lib.stream_ptr()),
-                                            "y5m_s2d_input"), ()))
+        self.fwd.append((_kind(lambda: _lib.check(L.y5m_s2d_input(_lib.ptr(self.x_in), B, H, W, s2d.ptr, dt, _lib.stream_ptr()),
+                                                  "y5m_s2d_input"), "input"), ()))
         f = first_out
         # concat buffers of the PANet joins (model.py:226, :230); producers write their slices in place
         cat1 = self._new_act(B, H // 16, W // 16, 16 * f)     # [up(neck0) | backbone6]
@@ -861,7 +898,7 @@ class Engine:
             self.accf = torch.zeros((self._accf,), dtype=torch.float64, device=self.dev)
             for a, off in self._acc_users:
                 a.bn_acc = self.accf.data_ptr() + 8 * off
-            self.fwd.insert(0, (lambda: self.accf.zero_(), ()))
+            self.fwd.insert(0, (_kind(lambda: self.accf.zero_(), "fill"), ()))
         if self.training:
             self.scratch2 = [torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev) for _ in range(self.nslots)]
             self.scratch = self.scratch2[0]
@@ -870,8 +907,8 @@ class Engine:
             self._accb_base = (self._gw_floats + 1) // 2 * 2
             self.gw = torch.zeros((self._accb_base + (2 * self._accb if self.fuse_b else 0),), dtype=torch.float32, device=self.dev)
             # expand the backward stack in reverse order; plan-time gradient-written flags
-            self.bwd.append((lambda: self.gw.zero_(), ()))
-            self.bwd.append((lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, ()))
+            self.bwd.append((_kind(lambda: self.gw.zero_(), "fill"), ()))
+            self.bwd.append((_kind(lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, "fill"), ()))
             # bwd_marks[i] = (op index after which unit i's parameter gradients are final, unit name,
             # device address of its weight gradient inside the flat buffer) -- in backward order
             self.bwd_marks = []
