@@ -59,6 +59,23 @@ def test_forward_f32_golden(golden, tag, shape, mode):
         assert int(sd["backbone.0.cbl.1.num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 2e-2)])
+def test_eval_merged_c3_pair_equals_two_convs(dtype, tol, monkeypatch):
+    """eval mode runs C3's c_skipped + c1 (reference model.py:77, :69) as ONE folded conv writing two slices of a 3-slice
+    buffer (engine._cbl_pair_eval); Y5M_MERGE_C3=0 runs them as the reference does, as two convs"""
+    x = synth_images(2, 96, 128).to(DEV)
+    outs = []
+    for merge in ("1", "0"):
+        monkeypatch.setenv("Y5M_MERGE_C3", merge)
+        m = _model(dtype).eval()
+        with torch.no_grad():
+            outs.append([t.float().cpu() for t in m(x)])
+        eng = m._engine_for(x)
+        assert any("+" in l.name for l in eng.layers) == (merge == "1")
+    for a, b in zip(*outs):
+        assert float((a - b).norm() / b.norm()) <= tol, (dtype, float((a - b).norm() / b.norm()))
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_forward_bf16_vs_oracle(mode):
     m = _model("bf16")
