@@ -366,7 +366,15 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
             // 96x48 wave tile -- is: 25 / 38 / 50 / 62 / 75 / 100 / 150 % = +2.3 / +0.2 / 0 / +0.15 / +0.1 / +0.35 / +0.5 ms per step
             static int res_pct = -1;
             if (res_pct < 0) { const char* e = getenv("Y5M_WGRAD_RES_PCT"); res_pct = e ? atoi(e) : 50; }
-            ks = (NFR != 6 ? 1024 : resident) * res_pct / 100 / base;
+            // Y5M_WGRAD_ROUND: 0 = budget / tiles rounded down, 1 = to the nearest, 2 (default) = down, except that ONE block per tile
+            // becomes two when the budget covers 1.5 tiles' worth: 384 -> 768 stride 2 has 144 tiles, and 256 / 144 rounded down left it
+            // on 144 of the 256 CUs (362 us alone, 276 with two; MIOpen's best solver 238). Inside the step: 2 = -0.05 ms against 0 (three
+            // alternating rounds), 1 = +0.2 ms (the 72-tile layers go from 216 to 288 blocks: fewer blocks is better next to the main stream).
+            static int rnd = -1;
+            if (rnd < 0) { const char* e = getenv("Y5M_WGRAD_ROUND"); rnd = e ? atoi(e) : 2; }
+            const int budget = (NFR != 6 ? 1024 : resident) * res_pct / 100;
+            ks = (budget + (rnd == 1 ? base / 2 : 0)) / base;
+            if (rnd == 2 && ks == 1 && 2 * budget >= 3 * base) ks = 2;
         }
         const int maxks = (chunks + minch - 1) / minch;
         ks = ks > maxks ? maxks : ks;
