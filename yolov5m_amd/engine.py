@@ -317,7 +317,7 @@ class Engine:
 
         def backward(lay=lay, P=P, need_dx=need_dx):
             if (self.fused_pw and self.fuse_b and need_dx and lay.kk == 1 and lay.ss == 1 and lay.res is None
-                    and not lay.stem and not self.ablate):
+                    and not lay.stem and not (self.ablate & {"wgrad_pw", "wgrad_3x3"})):
                 fops = self._bwd_pw_ops(lay.x, lay.y_ptr, lay.y_ld, lay.wd[0][0], [(lay, P)], lay.M, lay.cout)
                 if fops is not None:
                     return fops
@@ -669,7 +669,7 @@ class Engine:
                            ctypes.c_void_p(wd.data_ptr() + lay.off * esz), wd.shape[0], cols, 0, dt, wd.shape[1])
 
         def backward():
-            if self.fused_pw and self.fuse_b and need_dx and not self.ablate:
+            if self.fused_pw and self.fuse_b and need_dx and not (self.ablate & {"wgrad_pw", "wgrad_3x3"}):
                 fops = self._bwd_pw_ops(x, y2.data_ptr(), N2, wd, halves, M, N2)
                 if fops is not None:
                     return fops
@@ -918,7 +918,7 @@ class Engine:
                 for name, addr in self._grad_done[n0:]:
                     self.bwd_marks.append((len(self.bwd), name, addr))
             for sl in range(self.nslots):
-                self.bwd.append((self._join_op(sl), ()))
+                self.bwd.append((self._join_op(sl, final=True), ()))
             if os.environ.get("Y5M_WGRAD_AFTER_DGRAD", "1") == "1":
                 # fork the weight gradient AFTER the layer's data-gradient launches: it then runs next to the following
                 # layer's HBM-bound BatchNorm backward instead of next to the MFMA-bound data gradient it would only
@@ -954,7 +954,7 @@ class Engine:
         (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
         hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
         if wa is not None and self.ablate:
-            # Y5M_ABLATE (TIMING ONLY, gradients WRONG): drop weight-gradient launches by class -- parameters then only see weight
+            # Y5M_ABLATE (TIMING ONLY, gradients WRONG; `joins`: see _join_op): drop weight-gradient launches by class -- parameters then only see weight
             # decay, the activations / gradients flowing through the step keep their values (tools/ab_step.sh)
             taps = wa.th * wa.tw
             if ("wgrad_pw" in self.ablate and taps == 1) or ("wgrad_3x3" in self.ablate and taps > 1):
@@ -986,10 +986,10 @@ class Engine:
         run.wa = wa                     # the y5m_wgrad_args of this launch (bench.py: per-kernel roofline)
         return run
 
-    def _join_op(self, slot):
+    def _join_op(self, slot, final=False):
         def run():
             ev = self._pending.pop(slot, None)
-            if ev is not None:
+            if ev is not None and (final or "joins" not in self.ablate):     # Y5M_ABLATE=joins (TIMING ONLY: dy slots race)
                 torch.cuda.current_stream().wait_event(ev)
         run.kind = "join"
         return run
