@@ -414,6 +414,41 @@ def test_conv_wgrad_wide_layers(case):
     assert _relerr(got, w.grad) < TOL["bf16"], (case, ops.LAST_WGRAD_KERNEL, _relerr(got, w.grad))
 
 
+# ---- wgrad_rows_kernel: 3x3 weight gradients of the layers with 48 input channels, one kernel row per block, runs of 32 output
+# pixels of one row. Widths that are not a multiple of 32 (masked run tails), a single partial run per row, stride 2 with odd
+# input sizes, 48 and 96 output channels (4 x 1 and 2 x 2 wave arrangements), enough pixels for several chunks per pixel range.
+WGRAD_ROWS_CASES = [
+    # B, Cin, H, W, Cout, k, s, p
+    (2, 48, 12, 40, 48, 3, 1, 1),
+    (1, 48, 9, 17, 48, 3, 1, 1),
+    (3, 48, 20, 64, 48, 3, 1, 1),
+    (2, 48, 24, 50, 96, 3, 2, 1),
+    (1, 48, 11, 13, 96, 3, 2, 1),
+    (4, 48, 64, 64, 96, 3, 2, 1),
+    (2, 48, 16, 96, 96, 3, 1, 1),
+    (2, 48, 33, 70, 48, 3, 2, 1),
+    (8, 48, 80, 80, 96, 3, 2, 1),
+    (8, 48, 40, 40, 48, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_ROWS_CASES)
+def test_conv_wgrad_rows_kernel(case):
+    from yolov5m_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    x = _q(_rand((B, Cin, H, W), 31), "bf16")
+    w = _rand((Cout, Cin, k, k), 32, -0.2, 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = _q(_rand(tuple(y.shape), 33), "bf16")
+    y.backward(dy)
+    got = ops.conv_wgrad(dy.to(DEV), x.to(DEV), k, s, p, "bf16").cpu()
+    assert ops.LAST_WGRAD_KERNEL.startswith("wgrad_rows_kernel"), ops.LAST_WGRAD_KERNEL
+    assert _relerr(got, w.grad) < TOL["bf16"], (case, ops.LAST_WGRAD_KERNEL, _relerr(got, w.grad))
+    # per tap: an error confined to one tap (a wrong row offset / stride) must not hide in the norm of the other eight
+    for t in range(9):
+        assert _relerr(got[:, :, t // 3, t % 3], w.grad[:, :, t // 3, t % 3]) < TOL["bf16"], (case, t)
+
+
 # ---- fused pointwise backward (csrc/y5m_bwd_pw.hip): BatchNorm+SiLU backward apply + data gradient + weight gradient of a
 # 1x1 CBL in one launch, against torch autograd of the same layer on the same bf16 operands. Channel counts 48 / 96 / 192
 # (the three tile geometries), pixel counts that leave a tile tail and that give some workgroups no tile at all, two

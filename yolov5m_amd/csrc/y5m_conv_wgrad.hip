@@ -401,11 +401,242 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad_rows_kernel: the 3x3 weight gradients of the layers with 48 INPUT channels (48 -> 48 stride 1 and 48 -> 96 stride 2 at
+// 160x160; bf16). With one tap per block (wgrad_kernel) these launches re-stage dY and X nine times through L2 and are bound by
+// that traffic (48 -> 96: 4.2 GB of L2 reads for 0.94 GB of operands, 405 us alone on the chip). Here a block owns ONE KERNEL ROW ty:
+//   * pixels are taken in RUNS of 32 consecutive output pixels of one output row; the X pixels the run's three horizontal taps
+//     touch are 32*S + 2 CONSECUTIVE input pixels of ONE input row -- staged once, as they lie in memory (no per-tap gather), and
+//     tap tx reads them from LDS at pixel offset tx with pixel stride S (every lane of a transposing read supplies its own row
+//     address, so offset and stride are free);
+//   * the run's dY tile is staged once for the three taps: dY is read 3x instead of 9x, X 1.5x (stride 2) / 3x (stride 1);
+//   * a wave holds 3 taps x 48 x 48 outputs (27 accumulator fragments); the 4 waves are WN (48 dY channels each) x WK (runs of a
+//     chunk), WK partial tiles are added in LDS before ONE set of atomics per block.
+template <int WN, int WK, int S>
+struct WrCfg {
+    static constexpr int N = WN * 48;                   // dY channels (all of them in one block)
+    static constexpr int NPX = 32 * S + 2;              // X pixels of a run
+    static constexpr int XG = NPX * 32 + 64;            // bytes of one 16-channel group of a run's X pixels (+64: groups on other banks)
+    static constexpr int YB = WK * (N / 16) * WG_SUB;   // dY tile: [run][16-channel group][32 pixel][16 channel]
+    static constexpr int XB = WK * 3 * XG;              // X tile:  [run][16-channel group][NPX pixel][16 channel]
+    static constexpr int YP = WK * 32 * (N / 8);        // 16-byte pieces per chunk
+    static constexpr int XP = WK * NPX * 6;
+    static constexpr int NLDY = (YP + 255) / 256, NLDX = (XP + 255) / 256;
+    static constexpr int TILE_F = 27 * 4 * 64;          // floats of one wave's accumulators
+    static constexpr int RED = (WK / 2) * WN * TILE_F * 4;
+    static constexpr int LDS = (YB + XB) > RED ? (YB + XB) : RED;
+};
+
+template <int WN, int WK, int S>
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, const int spr, const int nruns) {
+    using C = WrCfg<WN, WK, S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid % WN, wk = wid / WN;
+    // the three kernel-row blocks of one pixel range are consecutive logical ids on one XCD (they share dY through its L2)
+    const int nblk = gridDim.x, hb = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = hb & 7;
+    const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hb >> 3);
+    const int ty = bid % 3, ksp = bid / 3;
+    const int chunks_total = (nruns + WK - 1) / WK;
+    const int per = (chunks_total + P.ksplit - 1) / P.ksplit;
+    const int ch_lo = ksp * per, ch_hi = min(chunks_total, ch_lo + per);
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(P.dy), 0, (unsigned)((size_t)P.M * P.lddy * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(P.x), 0, (unsigned)((size_t)P.B * P.Hin * P.Win * P.ldx * 2), 0x00020000);
+    // piece -> (run of the chunk, pixel of the run, 16-byte channel piece): loop invariant
+    int yks[C::NLDY], ypx[C::NLDY], ycc[C::NLDY], xks[C::NLDX], xpx[C::NLDX], xcc[C::NLDX];
+#pragma unroll
+    for (int i = 0; i < C::NLDY; ++i) {
+        const int q = tid + 256 * i;
+        yks[i] = q < C::YP ? q / (32 * (C::N / 8)) : -1;
+        const int rem = q % (32 * (C::N / 8));
+        ypx[i] = rem / (C::N / 8);
+        ycc[i] = rem % (C::N / 8);
+    }
+#pragma unroll
+    for (int i = 0; i < C::NLDX; ++i) {
+        const int q = tid + 256 * i;
+        xks[i] = q < C::XP ? q / (C::NPX * 6) : -1;
+        const int rem = q % (C::NPX * 6);
+        xpx[i] = rem / 6;
+        xcc[i] = rem % 6;
+    }
+    const float rcpS = 1.0f / (float)spr, rcpH = 1.0f / (float)P.Hg;
+    const unsigned ldyb = (unsigned)(P.lddy * 2), ldxb = (unsigned)(P.ldx * 2);
+    const int dh = P.dh0 + ty * P.dhs;
+    u32x4 ry[C::NLDY], rx[C::NLDX];
+    auto load_chunk = [&](int chk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::NLDY; ++i) {
+            const int u = chk * WK + yks[i];
+            int row, j;
+            fast_divmod(u, spr, rcpS, row, j);                        // row = b * Hg + oy
+            const int ox = 32 * j + ypx[i];
+            const bool ok = yks[i] >= 0 && u < nruns && ox < P.Wg;
+            const unsigned m = (unsigned)(row * P.Wg + ox);
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, ok ? m * ldyb + (unsigned)(ycc[i] * 16) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::NLDX; ++i) {
+            const int u = chk * WK + xks[i];
+            int row, j, b, oy;
+            fast_divmod(u, spr, rcpS, row, j);
+            fast_divmod(row, P.Hg, rcpH, b, oy);
+            const int iy = oy * P.sy + dh, ix = 32 * j * P.sx + P.dw0 + xpx[i];
+            const bool ok = xks[i] >= 0 && u < nruns && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            const unsigned pix = __umul24((unsigned)(b * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? __umul24(pix, ldxb) + (unsigned)(xcc[i] * 16) : OOB, 0, 0);
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        unsigned char* Ys = smem;
+        unsigned char* Xs = smem + C::YB;
+#pragma unroll
+        for (int i = 0; i < C::NLDY; ++i)
+            if (yks[i] >= 0)
+                *reinterpret_cast<u32x4*>(Ys + (yks[i] * (C::N / 16) + (ycc[i] >> 1)) * WG_SUB + ypx[i] * 32 + (ycc[i] & 1) * 16) = ry[i];
+#pragma unroll
+        for (int i = 0; i < C::NLDX; ++i)
+            if (xks[i] >= 0)
+                *reinterpret_cast<u32x4*>(Xs + (xks[i] * 3 + (xcc[i] >> 1)) * C::XG + xpx[i] * 32 + (xcc[i] & 1) * 16) = rx[i];
+    };
+
+    f32x4 acc[3][3][3];                                   // [tap tx][dY fragment][X fragment]
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = 4 * (lane >> 4) + ((lane & 15) >> 2), lb = (lane & 3) * 8;
+    const int y_off = lrow * 32 + lb, x_off = S * lrow * 32 + lb;
+    auto tr8 = [&](const unsigned char* p, int second) __attribute__((always_inline)) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p + second));
+        return make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+    };
+    auto compute = [&]() __attribute__((always_inline)) {
+        const unsigned char* Ys = smem + (wk * (C::N / 16) + wn * 3) * WG_SUB + y_off;
+        const unsigned char* Xs = smem + C::YB + wk * 3 * C::XG + x_off;
+        uint4 ya[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ya[a] = tr8(Ys + a * WG_SUB, 512);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            uint4 xb[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) xb[b] = tr8(Xs + b * C::XG + t * 32, S * 512);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ya[a]),
+                                                                           __builtin_bit_cast(bf16x8_t, xb[b]), acc[t][a][b], 0, 0, 0);
+        }
+    };
+
+    if (ch_lo < ch_hi) {
+        load_chunk(ch_lo);
+        store_chunk();
+        __syncthreads();
+        for (int chk = ch_lo; chk < ch_hi; ++chk) {
+            const bool more = chk + 1 < ch_hi;
+            if (more) load_chunk(chk + 1);
+            compute();
+            __syncthreads();
+            if (more) store_chunk();
+            __syncthreads();
+        }
+    }
+    // the WK waves of a channel group add their tiles pairwise in LDS (wk >= st writes, wk - st adds), then wk == 0 issues the atomics
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int st = WK / 2; st >= 1; st >>= 1) {
+        __syncthreads();
+        if (wk >= st && wk < 2 * st) {
+            float* d = red + ((size_t)(wk - st) * WN + wn) * C::TILE_F + lane;
+#pragma unroll
+            for (int f = 0; f < 27; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[(f * 4 + r) * 64] = acc[f / 9][(f / 3) % 3][f % 3][r];
+        }
+        __syncthreads();
+        if (wk < st) {
+            const float* sp = red + ((size_t)wk * WN + wn) * C::TILE_F + lane;
+#pragma unroll
+            for (int f = 0; f < 27; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[f / 9][(f / 3) % 3][f % 3][r] += sp[(f * 4 + r) * 64];
+        }
+    }
+    if (ch_lo < ch_hi && wk == 0) {
+        const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = wn * 48 + a * 16 + g * 4 + r;
+                        atomicAdd(P.dwgt + (size_t)n * P.lddw + (ty * 3 + t) * P.C + b * 16 + i, acc[t][a][b][r]);
+                    }
+    }
+}
+
+template <int WN, int WK, int S>
+static int launch_wgrad_rows(WgradParams& P, hipStream_t st) {
+    using C = WrCfg<WN, WK, S>;
+    const int spr = (P.Wg + 31) / 32;                    // runs per output row
+    const int nruns = P.B * P.Hg * spr;
+    const int chunks = (nruns + WK - 1) / WK;
+    if (P.ksplit <= 0) {
+        static int target = -1;                           // Y5M_WGRAD_ROWS_BLOCKS: blocks of a launch (3 kernel rows x pixel ranges)
+        if (target < 0) { const char* e = getenv("Y5M_WGRAD_ROWS_BLOCKS"); target = e ? atoi(e) : 512; }
+        int ks = target / 3;
+        const int maxks = (chunks + 7) / 8;               // >= 8 chunks per block
+        ks = ks > maxks ? maxks : ks;
+        P.ksplit = ks < 1 ? 1 : ks;
+    }
+    P.tiles_n = P.tiles_c = 1;
+    auto kern = wgrad_rows_kernel<WN, WK, S>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        attr = true;
+    }
+    Y5M_NAME_ONLY(Y5M_OK, "wgrad_rows_kernel<%d,%d,%d>", WN, WK, S);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(3 * P.ksplit)), dim3(256), C::LDS, st, P, spr, nruns);
+    Y5M_CHECK_LAUNCH("wgrad_rows_kernel");
+    return Y5M_OK;
+}
+
+// 1 when the launch qualifies for wgrad_rows_kernel
+static bool wgrad_rows_eligible(const WgradParams& P) {
+    static int on = -1;                                   // Y5M_WGRAD_ROWS=0: one tap per block (wgrad_kernel) as before (A/B runs)
+    if (on < 0) { const char* e = getenv("Y5M_WGRAD_ROWS"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on && P.th == 3 && P.tw == 3 && P.dhs == 1 && P.dws == 1 && P.C == 48 && (P.N == 48 || P.N == 96) && P.sy == P.sx &&
+           (P.sy == 1 || P.sy == 2) && P.ldx % 8 == 0 && P.lddy % 8 == 0 && P.Hg > 0 && P.Wg > 0 &&
+           (long long)P.B * P.Hg * ((P.Wg + 31) / 32) < (1ll << 24);
+}
+
 template <typename T>
 static int dispatch_wgrad(WgradParams& P, hipStream_t st) {
     const bool n48 = P.N <= 48, c48 = P.C <= 48, c16 = P.C <= 16;
     const int taps = P.th * P.tw;
     if (taps % 9 == 0 && n48 && c16) return launch_wgrad<T, 1, 1, 4, 9, 9>(P, st);      // stem: 48 x (9 taps x 16)
+    if constexpr (sizeof(T) == 2) {
+        if (wgrad_rows_eligible(P)) {                      // 48 input channels, 3x3: one kernel row per block (wgrad_rows_kernel)
+            if (P.N == 48) return P.sy == 1 ? launch_wgrad_rows<1, 4, 1>(P, st) : launch_wgrad_rows<1, 4, 2>(P, st);
+            return P.sy == 1 ? launch_wgrad_rows<2, 2, 1>(P, st) : launch_wgrad_rows<2, 2, 2>(P, st);
+        }
+    }
     // (3 taps x 48 channels per block was measured too: the 108 accumulator registers leave one block per
     //  CU and the 48-channel 3x3 layers get SLOWER, 254 -> 447 us; only the stem's 16-channel input pays)
     if (n48 && c16) return launch_wgrad<T, 1, 1, 4, 1>(P, st);     // 48 x 16
