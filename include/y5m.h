@@ -274,6 +274,27 @@ typedef struct {
 int y5m_bwd_pw(const y5m_bwd_pw_args* args, int dtype, void* stream);
 int y5m_bwd_pw_eligible(const y5m_bwd_pw_args* args, int dtype);    /* 1 when y5m_bwd_pw accepts these arguments */
 
+/* Fused backward of the STEM CBL (csrc/y5m_bwd_stem.hip; reference model.py:181 CBL(3, first_out, 6, 2, 2), executed as a
+ * 3x3 / stride 1 / pad 1 conv over the 16-channel space-to-depth image; bf16): dy = BatchNorm+SiLU backward of (dz, y) is formed
+ * in registers and never stored (the stem has no data gradient); dwgt[n][tap * C + c] += sum_m dy[m][n] x[pix(m, tap)][c], f32
+ * atomics into the ZEROED packed gradient (the layout y5m_wgrad writes, y5m_unpack_wgrad mode 2 reads); dgamma / dbeta are written.
+ * The BatchNorm reduction must have been accumulated into acc by y5m_bn_bwd_fused_phase(..., phase = 1) ahead of this call. */
+typedef struct {
+    const void* dz;            /* [M][lddz] gradient wrt the CBL output, M = B * H * W                                     */
+    const void* y;             /* [M][ldy]  raw conv output                                                                */
+    const void* x;             /* [M][ldx]  conv input: the space-to-depth image (same pixel grid: stride 1, pad 1)        */
+    float* dwgt;               /* [N][lddw] packed f32 weight gradient, accumulated atomically                             */
+    int32_t B, H, W;
+    int32_t lddz, ldy, ldx, lddw;
+    int32_t N, C;              /* 48 output channels, 16 input channels per tap                                            */
+    int32_t act, pad_, pad2_;
+    const double* acc;         /* [y5m_bn_acc_slots()][2][N] f64 rows of the reduce pass                                   */
+    const float* scale; const float* shift; const float* mean; const float* invstd;   /* [N], forward statistics       */
+    float* dgamma; float* dbeta;                                                       /* [N] outputs (may be NULL)      */
+} y5m_bwd_stem_args;
+int y5m_bwd_stem(const y5m_bwd_stem_args* args, void* stream);
+int y5m_bwd_stem_eligible(const y5m_bwd_stem_args* args);           /* 1 when y5m_bwd_stem accepts these arguments */
+
 /* Weight layout conversion. master f32 [Cout][Cin][KH][KW] (the reference state_dict layout,
  * model.py:15) -> packed K-contiguous rows in compute dtype.
  *   mode 0: forward rows  dst[co][(ta*tw+tb)*Cin + ci]   (kh = kh0+ta*khs, kw = kw0+tb*kws)

@@ -499,6 +499,42 @@ def test_bwd_pw_fused(case, mode):
     np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=2e-3, atol=2e-3 * float(b_.grad.abs().max()))
 
 
+# ---- fused stem backward (csrc/y5m_bwd_stem.hip): BatchNorm+SiLU backward apply + 9-tap weight gradient of the stem in its executed
+# form (3x3 / stride 1 / pad 1 over a 16-channel image, 48 output channels), against torch autograd on the same bf16 operands.
+# Widths that are / are not multiples of the 32-pixel run, fewer chunks than workgroups and several chunks per workgroup, a
+# single image row, and per-tap comparison (a wrong row segment / pixel offset must not hide in the other taps' norm).
+BWD_STEM_CASES = [(2, 24, 40), (1, 9, 17), (3, 1, 70), (4, 96, 96), (64, 64, 64), (1, 5, 32)]
+
+
+@pytest.mark.parametrize("case", BWD_STEM_CASES)
+def test_bwd_stem_fused(case):
+    from yolov5m_amd import ops
+    B, H, W = case
+    N, C = 48, 16
+    x = _q(_rand((B, C, H, W), 61, -1, 1), "bf16")
+    w = _rand((N, C, 3, 3), 62, -0.25, 0.25)
+    gamma, beta = _rand((N,), 63, 0.5, 1.5), _rand((N,), 64, -0.3, 0.3)
+    yq = _q(F.conv2d(x, _q(w, "bf16"), None, 1, 1), "bf16").requires_grad_(True)
+    dz = _q(_rand((B, N, H, W), 65, -1, 1), "bf16")
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.silu(F.batch_norm(yq, None, None, g_, b_, True, 0.03, 1e-3))
+    z.backward(dz)
+    dyq = _q(yq.grad, "bf16")                                       # dy reaches the MFMAs rounded to bf16
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dyq, 1, 1)
+    mean = yq.detach().mean((0, 2, 3))
+    var = yq.detach().var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    dev = lambda t: t.to(DEV)
+    dw, dg, db = ops.bwd_stem(dev(dz), dev(yq.detach()), dev(x), dev(scale), dev(shift), dev(mean), dev(invstd))
+    assert _relerr(dw.cpu(), dw_ref) < TOL["bf16"], (case, _relerr(dw.cpu(), dw_ref))
+    for t in range(9):
+        assert _relerr(dw.cpu()[:, :, t // 3, t % 3], dw_ref[:, :, t // 3, t % 3]) < TOL["bf16"], (case, t)
+    np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=2e-3, atol=2e-3 * float(g_.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=2e-3, atol=2e-3 * float(b_.grad.abs().max()))
+
+
 # ---- BatchNorm statistics through accumulator rows (y5m_conv_args.bn_acc + y5m_bn_act_fused, csrc/y5m_bnfuse.h): the conv
 # launch adds its channel sums as f64 atomics, the normalise launch derives scale / shift / mean / invstd and the running
 # statistics itself (reference model.py:17 BatchNorm2d(eps=1e-3, momentum=0.03) in train mode, :20 SiLU); against torch

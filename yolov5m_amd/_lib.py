@@ -58,6 +58,13 @@ class BwdPwArgs(ctypes.Structure):
                 [("seg", BwdPwSeg * 2)])
 
 
+class BwdStemArgs(ctypes.Structure):
+    """mirror of y5m_bwd_stem_args (include/y5m.h)"""
+    _fields_ = ([("dz", c_void_p), ("y", c_void_p), ("x", c_void_p), ("dwgt", c_void_p)] +
+                [(n, c_int) for n in ("B", "H", "W", "lddz", "ldy", "ldx", "lddw", "N", "C", "act", "pad_", "pad2_")] +
+                [(n, c_void_p) for n in ("acc", "scale", "shift", "mean", "invstd", "dgamma", "dbeta")])
+
+
 _zero_pages = {}
 
 
@@ -135,6 +142,8 @@ _SIGS = {
     "y5m_pack_weights_batched": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),
     "y5m_bwd_pw": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_bwd_pw_eligible": (c_int, [c_void_p, c_int]),
+    "y5m_bwd_stem": (c_int, [c_void_p, c_void_p]),
+    "y5m_bwd_stem_eligible": (c_int, [c_void_p]),
     "y5m_unpack_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y5m_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "y5m_s2d_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -125,6 +125,7 @@ class Engine:
         # pays ~30 us of prologue + weight-gradient atomics per launch, so on the 40x40 layers (102 400 pixels at B = 64) the
         # three-launch form next to the forked weight gradients is the faster one (tools/bwd_pw_bench.py, tools/ab_step.sh)
         self.fused_pw_min_m = int(os.environ.get("Y5M_BWD_PW_MIN_M", "200000"))
+        self.fused_stem = os.environ.get("Y5M_BWD_STEM", "1") != "0"         # the stem's bn apply + weight gradient as ONE launch (y5m_bwd_stem)
         self.wgrad_direct = os.environ.get("Y5M_WGRAD_DIRECT", "1") != "0"    # 1x1 layers: atomics straight into flat_grads
         self._direct_wgrads = 0          # C3: c1 + c_skipped as one GEMM (_cbl_pair)
         self._bwd_stack = []
@@ -321,6 +322,10 @@ class Engine:
                 fops = self._bwd_pw_ops(lay.x, lay.y_ptr, lay.y_ld, lay.wd[0][0], [(lay, P)], lay.M, lay.cout)
                 if fops is not None:
                     return fops
+            if lay.stem and self.fused_stem and self.fuse_b and not need_dx and not self.ablate:
+                fops = self._bwd_stem_ops(lay, P)
+                if fops is not None:
+                    return fops
             ops = []
             z = lay.z
             dz = z.grad
@@ -492,6 +497,44 @@ class Engine:
         ops.append((_kind(fused, "bwd_pw"), ()))
         self._direct_wgrads += 1
         self._written(x)
+        return ops
+
+    def _bwd_stem_ops(self, lay, P):
+        """launch list entries of the fused stem backward (y5m_bwd_stem): the BatchNorm reduction into the layer's accumulator
+        rows, ONE launch that forms dy in registers and adds the 9-tap weight gradient into the packed buffer, and the unpack
+        into the reference layout -- all on the main stream (the stem is the last unit of the backward pass: a forked weight
+        gradient would run alone behind it). Returns None when the arguments do not qualify."""
+        from ._lib import BwdStemArgs
+        L, dt, st = self.L, self.dtype, _lib.stream_ptr
+        if self.tdt != torch.bfloat16:
+            return None
+        dz, bn, x = lay.z.grad, lay.bn, lay.x
+        a = BwdStemArgs()
+        a.dz, a.y, a.x = dz.ptr, lay.y_ptr, x.ptr
+        a.dwgt = self.gw.data_ptr() + 4 * lay.gw_off
+        a.B, a.H, a.W, a.lddz, a.ldy, a.ldx, a.lddw = x.B, x.H, x.W, dz.ld, lay.y_ld, x.ld, lay.ldgw
+        a.N, a.C, a.act = lay.cout, x.C, ACT_SILU
+        a.acc = self.gw.data_ptr() + 4 * self._accb_base + 8 * lay.accb_off
+        a.scale, a.shift, a.mean, a.invstd = (bn[k].data_ptr() for k in range(4))
+        a.dgamma, a.dbeta = P["gg"].data_ptr(), P["gb"].data_ptr()
+        if lay.Ho != x.H or lay.Wo != x.W or not L.y5m_bwd_stem_eligible(ctypes.byref(a)):
+            return None
+        ops = list(self._flush_lazy(lay.z))
+
+        def reduce():
+            _lib.check(L.y5m_bn_bwd_fused_phase(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(),
+                                                bn[2].data_ptr(), bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, None, None, 0,
+                                                None, 0, a.acc, dt, st(), 1), "y5m_bn_bwd_fused_phase(reduce)")
+
+        def fused():
+            _lib.check(L.y5m_bwd_stem(ctypes.byref(a), st()), "y5m_bwd_stem")
+        fused.bs = a
+
+        def unpack():
+            _lib.check(L.y5m_unpack_wgrad(a.dwgt, lay.cout, lay.cin_real, lay.k, lay.k, 2, lay.ldgw, P["gw"].data_ptr(), st()),
+                       "y5m_unpack_wgrad")
+        ops += [(_kind(reduce, "bn_reduce"), ()), (_kind(fused, "bwd_stem"), ()), (_kind(unpack, "unpack"), ())]
+        self._grad_done.append((lay.name, P["gw"].data_ptr()))
         return ops
 
     def _wgrad_ops(self, lay, wa, unpacks):

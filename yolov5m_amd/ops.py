@@ -298,6 +298,41 @@ def bwd_pw(dz, y, x, w, scale, shift, mean, invstd, split=None, init=None, src=N
     return from_nhwc(dx), dw.view(C, C, 1, 1).clone(), dgamma, dbeta
 
 
+def bwd_stem(dz, y, x, scale, shift, mean, invstd):
+    """Fused backward of the stem CBL in its executed form (y5m_bwd_stem; bf16): dz, y (B,48,H,W) gradient wrt / raw output of a
+    3x3 / stride 1 / pad 1 conv over x (B,16,H,W) (the space-to-depth image); per-channel forward statistics as in bwd_pw. The
+    BatchNorm reduction is accumulated first (y5m_bn_bwd_fused_phase, phase 1). Returns dW (48,16,3,3), dgamma, dbeta."""
+    from ._lib import BwdStemArgs
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT["bf16"]
+    B, N, H, W = dz.shape
+    C = x.shape[1]
+    M = B * H * W
+    dev = dz.device
+    dzn, yn, xn = to_nhwc(dz, tdt), to_nhwc(y, tdt), to_nhwc(x, tdt)
+    slots = int(L.y5m_bn_acc_slots())
+    acc = torch.zeros((slots, 2, N), dtype=torch.float64, device=dev)
+    st = [t.contiguous().float() for t in (scale, shift, mean, invstd)]
+    _lib.check(L.y5m_bn_bwd_fused_phase(dzn.data_ptr(), N, yn.data_ptr(), N, _lib.ptr(st[0]), _lib.ptr(st[1]), _lib.ptr(st[2]),
+                                        _lib.ptr(st[3]), M, N, ACT_SILU, None, None, 0, None, 0, _lib.ptr(acc), dt,
+                                        _lib.stream_ptr(), 1), "y5m_bn_bwd_fused_phase(reduce)")
+    gp = torch.zeros((N, 9 * C), dtype=torch.float32, device=dev)
+    dgamma = torch.full((N,), float("nan"), dtype=torch.float32, device=dev)
+    dbeta = torch.full((N,), float("nan"), dtype=torch.float32, device=dev)
+    a = BwdStemArgs()
+    a.dz, a.y, a.x, a.dwgt = dzn.data_ptr(), yn.data_ptr(), xn.data_ptr(), gp.data_ptr()
+    a.B, a.H, a.W, a.lddz, a.ldy, a.ldx, a.lddw, a.N, a.C, a.act = B, H, W, N, N, C, 9 * C, N, C, ACT_SILU
+    a.acc = acc.data_ptr()
+    a.scale, a.shift, a.mean, a.invstd = (t.data_ptr() for t in st)
+    a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    assert L.y5m_bwd_stem_eligible(ctypes.byref(a)) == 1
+    _lib.check(L.y5m_bwd_stem(ctypes.byref(a), _lib.stream_ptr()), "y5m_bwd_stem")
+    out = torch.zeros((N, C, 3, 3), dtype=torch.float32, device=dev)
+    _lib.check(L.y5m_unpack_wgrad(_lib.ptr(gp), N, C, 3, 3, 0, 9 * C, _lib.ptr(out), _lib.stream_ptr()), "y5m_unpack_wgrad")
+    torch.cuda.synchronize()
+    return out, dgamma, dbeta
+
+
 def sppf_pool(x, dtype="f32"):
     """x (B,C,H,W) -> the three cascaded MaxPool2d(5,1,2) outputs (reference model.py:108-110) in one native launch"""
     L = _lib.lib()
