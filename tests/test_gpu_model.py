@@ -941,4 +941,8 @@ def test_train_loop_mirror_runs_both_input_paths():
     p0 = torch.cat([p.detach().reshape(-1) for p in _model("f32").parameters()]).cpu()
     d0, d1 = results[0][1] - p0, results[1][1] - p0
     assert float(d0.abs().max()) > 0                       # the epoch's last batch forced one optimizer step (:116)
-    assert float((d0 - d1).abs().max()) <= 1e-3 * float(d0.abs().max())
+    # The two input paths feed images that differ in the last bit; Adam's first step (lr * g / (|g| + eps)) turns that into up to
+    # ~1 % of one update on the few elements whose gradient is itself rounding noise (tools/adam_noise.py): bound the update as a
+    # whole tightly and the single worst element loosely
+    assert float((d0 - d1).norm()) <= 1e-4 * float(d0.norm())
+    assert float((d0 - d1).abs().max()) <= 1e-2 * float(d0.abs().max())

@@ -84,8 +84,17 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
 #else
 #define Y5M_EXPF __expf
 #endif
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + Y5M_EXPF(-x)); }
+// 1 / x by the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the IEEE division (v_rcp + 2 Newton steps + fix-up, ~10 VALU):
+// sigmoid's denominator is in [1, inf), no denormal / overflow corner. Inside the step the BatchNorm / SiLU passes and the fused
+// backward kernels share their CUs with the forked weight gradient: -0.13 ms per step for the fused kernels alone.
+// (-DY5M_IEEE_RCP: A/B build with the division.)
+#ifdef Y5M_IEEE_RCP
+#define Y5M_RCPF(x) (1.0f / (x))
+#else
+#define Y5M_RCPF(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ float silu_f(float x) { return x * Y5M_RCPF(1.0f + Y5M_EXPF(-x)); }
 __device__ __forceinline__ float silu_grad(float t) {
-    const float s = 1.0f / (1.0f + Y5M_EXPF(-t));
+    const float s = Y5M_RCPF(1.0f + Y5M_EXPF(-t));
     return s * (1.0f + t * (1.0f - s));
 }
