@@ -93,7 +93,8 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
 #else
 #define Y5M_RCPF(x) __builtin_amdgcn_rcpf(x)
 #endif
-__device__ __forceinline__ float silu_f(float x) { return x * Y5M_RCPF(1.0f + Y5M_EXPF(-x)); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return Y5M_RCPF(1.0f + Y5M_EXPF(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float silu_grad(float t) {
     const float s = Y5M_RCPF(1.0f + Y5M_EXPF(-t));
     return s * (1.0f + t * (1.0f - s));
