@@ -784,6 +784,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             LOAD8_STREAM<T>(dz + (m + u * stride) * lddz + c, g[u]);
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, yv[u]);
         }
+        if constexpr (!FUSED) __builtin_amdgcn_sched_barrier(0);   // (this variant's straight-line body otherwise gets its loads sunk in front of their uses)
         finish4();
     }
     for (; m < M; m += stride) {
