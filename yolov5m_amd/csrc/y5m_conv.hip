@@ -244,6 +244,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
         }
     }
 
+    // folded BatchNorm of the lane's channels (EPI_AFFINE_ACT): loaded once per tile, not once per fragment and pixel row
+    float4 scv[NF], shv[NF];
+    const bool opnd = (P.epi == EPI_AFFINE_ACT && P.res != nullptr) || (P.epi == EPI_DGRAD && P.accumulate);
+    if (P.epi == EPI_AFFINE_ACT) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+            const int n = nb + cv_pch<NF>(a, fq * 4);
+            const bool ok = n < P.N;
+            scv[a] = ok ? *reinterpret_cast<const float4*>(P.scale + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            shv[a] = ok ? *reinterpret_cast<const float4*>(P.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     // dense output (no strided scatter): output pixel index == m, skip the decomposition
     const bool lin_out = P.epi != EPI_HEAD && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
                          P.Hout == P.Hg && P.Wout == P.Wg;
@@ -261,6 +273,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
         }
         float fv[NF][4];                 // finished values of the fragments that go to the dense / scattered T output
         unsigned okm = 0u;
+        // the pixel's residual (EPI_AFFINE_ACT) / read-modify-write operand (EPI_DGRAD accumulate: out = conv + (res ? res : out),
+        // `res` lets the first accumulation read ANOTHER tensor of the output's shape -- the bottleneck's residual gradient -- instead
+        // of a copy made beforehand): ALL fragments requested before the first is used, not one dependent round trip per fragment
+        float ov[NF][4];
+        if (opnd) {
+            const T* src = P.res ? reinterpret_cast<const T*>(P.res) + opix * P.ldres : reinterpret_cast<const T*>(P.out) + opix * P.ldout;
+#pragma unroll
+            for (int a = 0; a < NF; ++a) {
+                const int n = nb + cv_pch<NF>(a, fq * 4);
+                if (n < P.N) load4<T>(src + n, ov[a]);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
             const int n = nb + cv_pch<NF>(a, fq * 4);
@@ -288,29 +312,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
                 }
                 continue;
             }
-            T* o = reinterpret_cast<T*>(P.out) + opix * P.ldout + n;
             if (P.epi == EPI_AFFINE_ACT) {
-                const float4 sc = *reinterpret_cast<const float4*>(P.scale + n);
-                const float4 sh = *reinterpret_cast<const float4*>(P.shift + n);
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                v[0] = v[0] * scv[a].x + shv[a].x; v[1] = v[1] * scv[a].y + shv[a].y;
+                v[2] = v[2] * scv[a].z + shv[a].z; v[3] = v[3] * scv[a].w + shv[a].w;
                 if (P.act == Y5M_ACT_SILU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
                 }
-                if (P.res) {
-                    float rv[4];
-                    load4<T>(reinterpret_cast<const T*>(P.res) + opix * P.ldres + n, rv);
+            }
+            if (opnd) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                }
-            } else if (P.epi == EPI_DGRAD && P.accumulate) {
-                // out = conv + (res ? res : out): `res` lets the first accumulation read ANOTHER tensor of the
-                // output's shape (the bottleneck's residual gradient) instead of a copy made beforehand
-                float ov[4];
-                load4<T>(P.res ? reinterpret_cast<const T*>(P.res) + opix * P.ldres + n : o, ov);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += ov[r];
+                for (int r = 0; r < 4; ++r) v[r] += ov[a][r];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) fv[a][r] = v[r];

@@ -187,37 +187,47 @@ __global__ __launch_bounds__(GM_THREADS) void conv_gemm8_kernel(const ConvParams
                 }
             }
         }
+        float4 scv[EPI == EPI_AFFINE_ACT ? NF : 1], shv[EPI == EPI_AFFINE_ACT ? NF : 1];     // folded BatchNorm of the lane's channels: once per tile
+        if constexpr (EPI == EPI_AFFINE_ACT) {
+#pragma unroll
+            for (int a = 0; a < NF; ++a) {
+                scv[a] = *reinterpret_cast<const float4*>(P.scale + nb + gm_pch<NF>(a, fq * 4));
+                shv[a] = *reinterpret_cast<const float4*>(P.shift + nb + gm_pch<NF>(a, fq * 4));
+            }
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int m = em0 + wm * 64 + b * 16 + frow;
             if (m >= G.Mtot) continue;
             bf16_t* const ob = reinterpret_cast<bf16_t*>(P.out) + (size_t)m * P.ldout + nb;
             float fv[NF][4];
+            // the row's read-modify-write / residual operands: ALL fragments requested before the first is used (one load, one wait,
+            // one fragment at a time made the epilogue a chain of NF dependent memory round trips per row)
+            float ov[NF][4];
+            constexpr bool OPND = EPI == EPI_AFFINE_ACT || EPI == EPI_DGRAD;
+            const bool opnd = EPI == EPI_AFFINE_ACT ? P.res != nullptr : (EPI == EPI_DGRAD && P.accumulate);
+            if constexpr (OPND) {
+                if (opnd) {
+                    const bf16_t* src = P.res ? reinterpret_cast<const bf16_t*>(P.res) + (size_t)m * P.ldres + nb : ob;
+#pragma unroll
+                    for (int a = 0; a < NF; ++a) load4<bf16_t>(src + gm_pch<NF>(a, fq * 4), ov[a]);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < NF; ++a) {
-                const int nl = gm_pch<NF>(a, fq * 4), n = nb + nl;
                 float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
                 if constexpr (EPI == EPI_AFFINE_ACT) {
-                    const float4 sc = *reinterpret_cast<const float4*>(P.scale + n);
-                    const float4 sh = *reinterpret_cast<const float4*>(P.shift + n);
-                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                    v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                    v[0] = v[0] * scv[a].x + shv[a].x; v[1] = v[1] * scv[a].y + shv[a].y;
+                    v[2] = v[2] * scv[a].z + shv[a].z; v[3] = v[3] * scv[a].w + shv[a].w;
                     if (P.act == Y5M_ACT_SILU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
                     }
-                    if (P.res) {
-                        float rv[4];
-                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(P.res) + (size_t)m * P.ldres + n, rv);
+                }
+                if constexpr (OPND) {
+                    if (opnd) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                    }
-                } else if constexpr (EPI == EPI_DGRAD) {
-                    if (P.accumulate) {
-                        float ov[4];
-                        load4<bf16_t>(P.res ? reinterpret_cast<const bf16_t*>(P.res) + (size_t)m * P.ldres + n : ob + nl, ov);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += ov[r];
+                        for (int r = 0; r < 4; ++r) v[r] += ov[a][r];
                     }
                 }
 #pragma unroll
