@@ -356,7 +356,7 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
         else if (TPB > 1) ks = (256 * (per_cu < 1 ? 1 : per_cu) + base - 1) / base;
         else if (taps == 1) {
             static int pwb = -1;                            // Y5M_WGRAD_PW_BLOCKS: blocks of a pointwise weight gradient
-            if (pwb < 0) { const char* e = getenv("Y5M_WGRAD_PW_BLOCKS"); pwb = e ? atoi(e) : 160; }   // (swept 128..768 inside the full step: atomics-bound, fewer is better)
+            if (pwb < 0) { const char* e = getenv("Y5M_WGRAD_PW_BLOCKS"); pwb = e ? atoi(e) : 224; }   // (swept inside the full step; re-swept after the fused pointwise backward took the big 1x1 layers: 128 / 160 / 224 / 256 / 320 / 448 = +0.2 / +0.1 / 0 / +0.05 / +0.05 / +0.2 ms)
             ks = (pwb + base - 1) / base;
         }
         else if (C::TC <= 16) ks = (2048 + base - 1) / base;
