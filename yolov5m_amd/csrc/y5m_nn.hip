@@ -471,7 +471,7 @@ static inline EwGeom ew_geom(int64_t M, int C8, int max_gx, int threads = 256) {
 // producer launch added into, and every workgroup derives the coefficients of ITS channel group in a prologue (one L2
 // round trip + a little f64 arithmetic, next to the other resident workgroups' streaming); the workgroups with
 // blockIdx.x == 0 also write the per-channel arrays other launches read.
-#define BNF_EW_GX 1536       /* grid cap of the fused consumers (see y5m_bn_act_fused) */
+#define BNF_EW_GX 1024       /* grid cap of the fused consumers (see y5m_bn_act_fused); re-swept inside the step after the SiLU reciprocal change: 640 / 768 / 1024 / 1280 / 1536 / 2048 = +0.2 / 0 / 0 / +0.1 / +0.12 / +0.07 ms (Y5M_EW_GX) */
 struct BnFusedFwd {
     const double* acc; int ldacc;     // [BNF_SLOTS][2][ldacc], already offset to this layer's first channel
     double count;
