@@ -26,9 +26,13 @@ def test_dp_two_ranks_gradient_sum_and_identical_parameters():
     device; the collective calls are the same): the exchanged gradient == sum of the single-replica gradients, the
     bucketed exchange is overlapped with the backward segments (per-segment hipGraphs), parameters stay bit-identical
     across ranks, and the overlapped schedule lands where the plain one does. tools/dp_parity.py holds the checks."""
+    import socket
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", Y5M_DIST_BACKEND="gloo")
+    with socket.socket() as sk:                     # a free rendezvous port (a fixed one can still sit in TIME_WAIT from an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tools", "dp_parity.py")], env=env,
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dp_parity.py")], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "dp parity ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
