@@ -41,6 +41,10 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the persistent kernels (one workgroup per CU: halo-patch conv, long-K GEMM, fused backward kernels) leave 16 CUs to
+        # the collective's kernels when there IS a collective: on one GPU a cap of 224-240 CUs measured the same step time as all
+        # 256 (profiles/r03_knob_sweep.txt), so the headroom costs nothing; read once by the library (y5m_persistent_cus)
+        os.environ.setdefault("Y5M_PERSIST_CUS", "240")
         backend = backend or os.environ.get("Y5M_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             if backend != "nccl":
