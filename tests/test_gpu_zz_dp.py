@@ -12,6 +12,18 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (file name: collected AFTER test_gpu_model.py, so that `-x` never hides the model goldens behind a subprocess test)
+
+
+def _keep_log(tag, r):
+    """a failing child's complete stdout / stderr goes to gpurun_out/ (merged back from the GPU box): the assertion message
+    alone truncates it"""
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, f"{tag}_{os.getpid()}.log")
+    with open(path, "w") as f:
+        f.write(f"returncode {r.returncode}\n---- stdout ----\n{r.stdout}\n---- stderr ----\n{r.stderr}\n")
+    return path
 
 
 def test_rccl_allreduce_between_graphs_single_rank():
@@ -34,7 +46,10 @@ def test_dp_two_ranks_gradient_sum_and_identical_parameters():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dp_parity.py")], env=env,
                        capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "dp parity ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    if r.returncode != 0 or "dp parity ok" not in r.stdout:
+        path = _keep_log("dp_parity", r)
+        checks = [l for l in r.stdout.splitlines() if l.startswith("CHECK") or "FAILED" in l]
+        raise AssertionError((path, checks, r.stdout[-3000:], r.stderr[-3000:]))
 
 
 def test_bench_gpus_2_launches_two_ranks_itself():

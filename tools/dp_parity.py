@@ -18,6 +18,16 @@ from yolov5m_amd.utils.synth import synth_images, synth_labels, synth_state_dict
 rank, local, world = parallel.init_from_env()
 assert world > 1, "run under torch.distributed.run with --nproc-per-node >= 2"
 dev = f"cuda:{torch.cuda.current_device()}"
+FAILED = []
+
+
+def check(name, value, bound):
+    """every bound of this script goes through here: the value is printed on every rank (so a soak gives its distribution)
+    and a violation is recorded and reported at the end instead of hiding the later checks behind the first assert"""
+    ok = bool(value < bound)
+    print(f"CHECK rank{rank} {name} value {value:.3e} bound {bound:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    if not ok:
+        FAILED.append((name, value, bound))
 
 
 def model():
@@ -52,7 +62,7 @@ torch.cuda.synchronize()
 cuts = step.model._engines[next(iter(step.model._engines))]._cuts
 assert len(cuts) >= 1, cuts
 err = float((m.flat_grads - ref).abs().max() / ref.abs().max())
-assert err < 1e-4, ("summed gradient", err)
+check("summed_gradient_vs_replica_sum", err, 1e-4)
 g_overlapped = m.flat_grads.clone()
 
 # ---- 2. identical parameters after captured steps ------------------------------------------------------------------
@@ -63,8 +73,8 @@ assert step._opt_graph is not None and isinstance(step._fb_graphs[next(iter(step
 mine = m.flat_params.clone()
 gathered = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(gathered, mine)
-for g in gathered:
-    assert torch.equal(g, gathered[0]), "parameters differ across ranks"
+pdiff = max(float((g - gathered[0]).abs().max()) for g in gathered)
+check("parameters_differ_across_ranks_maxabs", pdiff, 1e-30)          # bit-identical: any difference fails
 assert bool(torch.isfinite(mine).all()) and float(lo[0]) == float(lo[0])
 st_ = hook.stats()
 assert st_ is not None and len(st_["buckets"]) == len(cuts) + 1 and st_["allreduce_exposed_ms"] >= 0.0, st_
@@ -78,17 +88,19 @@ torch.cuda.synchronize()
 # both schedules sum the same per-rank gradients of the same parameters: equal up to the order of the f32 atomic adds inside
 # the weight-gradient kernels (a bucket exchanged before its gradients were final, a wrong cut or a missed join would be O(1))
 gerr = float((m2.flat_grads - g_overlapped).abs().max() / g_overlapped.abs().max())
-assert gerr < 1e-4, ("overlapped vs plain exchanged gradient", gerr)     # (noise of the f32 atomic order, typically a few 1e-6. One full-suite run in about ten failed somewhere in this script -- the
-# message was not kept -- while the test passed alone before and after; this bound (was 2e-5) and the one below (was 2e-2) are the two
-# that depend on that noise, so they got headroom, and the test now takes a free rendezvous port)
+check("overlapped_vs_plain_exchanged_gradient", gerr, 2e-5)
 for _ in range(3):
     step2.step(x, t)
 torch.cuda.synchronize()
 p0 = torch.cat([p.detach().reshape(-1) for p in model().parameters()])
 d1, d2 = (mine - p0).cpu().numpy(), (m2.flat_params - p0).cpu().numpy()
 rel = np.linalg.norm(d1 - d2) / np.linalg.norm(d2)
-assert rel < 5e-2, ("overlapped vs plain exchange", rel)     # (four Adam steps: sign-like updates amplify 1e-6 gradient noise)
+check("overlapped_vs_plain_update_after_4_adam_steps", rel, 2e-2)     # (four Adam steps: sign-like updates amplify 1e-6 gradient noise)
 dist.barrier()
+if FAILED:
+    print(f"dp parity FAILED on rank {rank}: {FAILED}", flush=True)
+    dist.destroy_process_group()
+    sys.exit(1)
 if rank == 0:
     print(f"dp parity ok: world {world}, cuts {cuts}, grad err {err:.2e}, overlap-vs-plain gradient diff {gerr:.2e}, update diff {rel:.2e}")
 dist.destroy_process_group()

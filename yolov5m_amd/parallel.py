@@ -21,7 +21,7 @@ for. Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, point-to-point, no switch
     the reference's clip_grad_norm_(10) (train.py:118) is applied to that sum: with W ranks the clip engages at 1/W of
     the per-replica gradient norm -- the same as the single-process recipe on the W-times larger batch, whose loss is
     also a sum over images (ultralytics_loss.py:120). Rescale max_norm by W to keep the per-replica threshold instead;
-  * tools/dp_parity.py (tests/test_gpu_dp.py, two ranks): exchanged gradient == sum of the single-replica gradients,
+  * tools/dp_parity.py (tests/test_gpu_zz_dp.py, two ranks): exchanged gradient == sum of the single-replica gradients,
     parameters bit-identical across ranks after captured steps, overlapped == plain schedule. No scaling curve has been
     measured by this build (one GPU per box): the driver's SCALE run is the first multi-GPU execution.
 Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests). `Y5M_DIST_BACKEND=gloo`
