@@ -819,7 +819,7 @@ def test_native_gradient_accumulation_matches_torch(use_graph):
     step.step(xs[1], ts[1])
     p1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu().numpy()
     p0 = p_before.cpu().numpy()
-    p2 = m2.flat_params.cpu().numpy()
+    p2 = m2.flat_params.cpu().numpy().copy()          # (a copy also where .cpu() is the identity: the CPU executor of tests/emu)
     d1, d2 = p1 - p0, p2 - p0
     assert np.abs(d1).max() > 0
     _assert_same_update(d1, d2)

@@ -249,6 +249,14 @@ def require_cuda(*tensors):
             raise Y5MError("yolov5m_amd ops run on the MI355X only: got a CPU tensor (no CPU fallback).")
 
 
+DEVICE = "cuda"         # where the wrappers create their own tensors (there is no other choice: no CPU fallback)
+
+
+def require_cuda_device(dev):
+    if torch.device(dev).type != "cuda":
+        raise Y5MError("YOLOV5m runs on the MI355X only: call .to('cuda') first (no CPU fallback)")
+
+
 def int_array(vals):
     return (c_int * len(vals))(*[int(v) for v in vals])
 

@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A) {
             if (lane + 64 < A.nch) dst[lane + 64] = 0.0f;
         }
     } else if (GRAD) {
-        gsm[wid][lane] = gobj;                       // same-wave LDS traffic is in order: no barrier
+        gsm[wid][lane] = gobj;                       // same-wave LDS traffic is in order: no workgroup barrier
+        __builtin_amdgcn_wave_barrier();             // (no instruction: pins the order for the compiler -- and is the point where
+                                                     //  the CPU lane-level executor of tests/emu lets the other lanes catch up)
         if (c0 < S.cells) {
             const int ncell = (int)((S.cells - c0) < 64 ? (S.cells - c0) : 64);
             const int nelem = ncell * A.nch;

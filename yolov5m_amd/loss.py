@@ -68,8 +68,7 @@ class YOLO_LOSS:
         self.save_logs = save_logs
         self.filename = filename
         self.last_components = None
-        if not self.anchors_d.is_cuda:
-            raise _lib.Y5MError("YOLO_LOSS: model must live on the GPU (no CPU fallback)")
+        _lib.require_cuda(self.anchors_d)                     # (the model must live on the GPU: no CPU fallback)
         if self.save_logs and not resume:                                             # :51-62
             folder = os.path.join("train_eval_metrics", filename)
             os.makedirs(folder, exist_ok=True)

@@ -228,8 +228,7 @@ class YOLOV5m(nn.Module):
         dev = next(self.parameters()).device
         if self._flat_device == dev and self.flat_params is not None:
             return
-        if dev.type != "cuda":
-            raise _lib.Y5MError("YOLOV5m runs on the MI355X only: call .to('cuda') first (no CPU fallback)")
+        _lib.require_cuda_device(dev)
         params = list(self.parameters())
         n = sum(p.numel() for p in params)
         flat = torch.empty(n, dtype=torch.float32, device=dev)

@@ -116,8 +116,7 @@ class ComputeLoss:
 
     def _prep(self, p, targets):
         anchors = self.anchors
-        if not anchors.is_cuda:
-            raise _lib.Y5MError("ComputeLoss: model must live on the GPU (no CPU fallback)")
+        _lib.require_cuda(anchors)                            # (the model must live on the GPU: no CPU fallback)
         targets = torch.as_tensor(targets).to(anchors.device, non_blocking=True)     # :63
         targets = targets.float().reshape(-1, 6).contiguous()
         p = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous() for t in p]
