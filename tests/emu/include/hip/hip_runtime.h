@@ -297,18 +297,20 @@ typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x32_bf16: A[i][k] in lane (i = l & 15), k = 8 (l >> 4) + j; B[k][n] in lane (n = l & 15), same k;
 // D[i][n] in lane (n = l & 15), rows i = 4 (l >> 4) + r
 static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 acc, int, int, int) {
-    struct Op { emu_bf16x8 a, b; };
+    struct Op { float a[8], b[8]; };                  // widened once at the deposit: the 4 x 32 products per lane are plain f32
+    static_assert(sizeof(Op) <= emu::SLOT_BYTES, "slot");
     auto c = emu::coll_begin();
-    c.mine<Op>() = Op{a, b};
+    Op& me = c.mine<Op>();
+    for (int j = 0; j < 8; ++j) { me.a[j] = (float)a[j]; me.b[j] = (float)b[j]; }
     emu::coll_sync(6);
     const int n = c.lane & 15, g4 = c.lane >> 4;
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * g4 + r;
         float s = 0.0f;
         for (int q = 0; q < 4; ++q) {
-            const Op& oa = c.of<Op>(i + 16 * q);       // A row i, k = 8 q + j
-            const Op& ob = c.of<Op>(n + 16 * q);       // B column n, k = 8 q + j
-            for (int j = 0; j < 8; ++j) s += (float)oa.a[j] * (float)ob.b[j];
+            const float* pa = c.of<Op>(i + 16 * q).a;       // A row i, k = 8 q + j
+            const float* pb = c.of<Op>(n + 16 * q).b;       // B column n, k = 8 q + j
+            for (int j = 0; j < 8; ++j) s += pa[j] * pb[j];
         }
         acc[r] += s;
     }

@@ -1,0 +1,183 @@
+"""CPU: the engine's launch lists and the data-parallel step, executed on the CPU lane-level executor (tests/emu) -- the
+product's own engine.py / training_utils.py / parallel.py drive the product's own kernel sources on host tensors.
+
+  * plan invariants of the overlapped gradient exchange (Engine.bwd_marks / grad_cuts / _check_grad_writers), with and
+    without the weight-gradient reorder;
+  * the property the exchange relies on, by execution: once the backward list has run up to a cut, no later launch writes the
+    part of the flat gradient buffer that cut declares final (bit-exact before / after);
+  * two gloo ranks: NativeTrainStep's overlapped schedule (segments + bucket launches + wait) lands on the all-reduce of the
+    ranks' plain gradients, parameters stay bit-identical across ranks.
+What this cannot cover: streams, events, captured graphs, RCCL (launches are synchronous here) -- tests/test_gpu_zz_dp.py."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _model(dtype="bf16"):
+    from yolov5m_amd import config
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd.utils.synth import synth_state_dict
+    m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+    m.load_state_dict(synth_state_dict(), strict=True)
+    m.compute_dtype = dtype
+    m.train()
+    m.flatten_parameters()
+    return m
+
+
+@pytest.mark.parametrize("after_dgrad", ["1", "0"])
+def test_plan_marks_and_cuts(after_dgrad, monkeypatch):
+    from emu.harness import emulated
+    from yolov5m_amd import _lib
+    from yolov5m_amd.engine import Engine
+    monkeypatch.setenv("Y5M_WGRAD_AFTER_DGRAD", after_dgrad)
+    with emulated():
+        m = _model()
+        eng = Engine(m, 2, 64, 64, dtype=_lib.BF16, training=True)        # (_check_grad_writers runs inside)
+        n = m.flat_grads.numel()
+        ks = [k for k, _, _ in eng.bwd_marks]
+        assert ks == sorted(ks) and ks[-1] <= len(eng.bwd)
+        # every parameter-gradient writer of the list sits in front of its unit's mark; the reorder moved weight gradients
+        kinds = [getattr(op[0], "kind", None) for op in eng.bwd]
+        if after_dgrad == "1":
+            assert any(a == "conv_igemm" and b == "wgrad" for a, b in zip(kinds, kinds[1:]))
+        cuts = eng.grad_cuts()
+        assert len(cuts) == 2
+        (k1, lo1), (k2, lo2) = cuts
+        assert 0 < k1 < k2 < len(eng.bwd) and n > lo1 > lo2 > 0
+        assert n - lo1 >= 0.5 * n and n - lo2 >= 0.9 * n
+        marks = {k for k, _, _ in eng.bwd_marks}
+        assert k1 in marks and k2 in marks
+        # a cut never separates a unit's gradient writers from its mark
+        for k, _ in cuts:
+            assert kinds[k - 1] in Engine._GRAD_WRITER_KINDS + ("conv_igemm", "join")
+
+
+@pytest.mark.parametrize("min_m", ["200000", "0"])      # default dispatch at this size | every eligible 1x1 CBL on bwd_pw_kernel
+def test_gradients_behind_a_cut_are_final(min_m, monkeypatch):
+    """run the backward list cut by cut: what a cut declares final must not change afterwards (bit-exact)"""
+    monkeypatch.setenv("Y5M_BWD_PW_MIN_M", min_m)
+    from emu.harness import emulated
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.synth import synth_images, synth_labels
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    with emulated():
+        m = _model()
+        st = NativeTrainStep(m, ComputeLoss(m), nt_max=64)
+        eng = st.load_inputs(synth_images(2, 64, 64, seed="cut/img"), synth_labels(2, 4, seed="cut/lab"))
+        (k1, lo1), (k2, lo2) = eng.grad_cuts()
+        kinds = [getattr(op[0], "kind", None) for op in eng.bwd]
+        assert ("bwd_pw" in kinds) == (min_m == "0") and "bwd_stem" in kinds
+        flat = m.flat_grads
+        st._enqueue_fb(eng, bwd_upto=k1)
+        s1 = flat[lo1:].clone()
+        assert float(s1.abs().max()) > 0
+        eng._run(eng.bwd[k1:k2])
+        eng.join_all()
+        assert torch.equal(flat[lo1:], s1), "a launch behind the first cut wrote gradients that cut declared final"
+        s2 = flat[lo2:].clone()
+        eng._run(eng.bwd[k2:])
+        assert torch.equal(flat[lo2:], s2), "a launch behind the second cut wrote gradients that cut declared final"
+        assert float(flat[:lo2].abs().max()) > 0                      # (the last segment did write its own part)
+
+
+def test_plan_cache_retries_after_oom_outside_the_handler(monkeypatch):
+    """the retry after an out-of-memory plan build must run AFTER the except block (the traceback keeps the failed
+    plan alive inside it), with every resident plan released first"""
+    import gc
+    from emu.harness import emulated
+    import yolov5m_amd.engine as E
+    with emulated():
+        m = _model()
+        x = torch.zeros((1, 3, 64, 64))
+        first = m._engine_for(x)
+        real, calls, state = E.Engine, [], {}
+
+        def flaky(*a, **k):
+            calls.append(sys.exc_info()[0])              # the exception being handled at the time of the call, if any
+            if len(calls) == 1:
+                state["resident_at_first_try"] = len(m._engines)
+                raise torch.OutOfMemoryError("synthetic")
+            state["resident_at_retry"], state["first_released"] = len(m._engines), first.released
+            return real(*a, **k)
+        monkeypatch.setattr(E, "Engine", flaky)
+        eng = m._engine_for(torch.zeros((1, 3, 96, 64)))
+        assert len(calls) == 2 and calls[1] is None, "the retry ran inside the exception handler"
+        assert state["resident_at_first_try"] == 1 and state["resident_at_retry"] == 0 and state["first_released"]
+        assert not eng.released and list(m._engines.values()) == [eng]
+        gc.collect()
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), Y5M_EMU_THREADS="4")
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from emu.harness import emulated
+    from yolov5m_amd import parallel
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.synth import synth_images, synth_labels
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    try:
+        with emulated():
+            r, _, w = parallel.init_from_env(backend="gloo")
+            x, t = synth_images(2, 64, 64, seed=f"dp/img{rank}"), synth_labels(2, 4, seed=f"dp/lab{rank}")
+            # reference: this rank's plain gradient, summed over the ranks with ONE collective
+            m0 = _model()
+            s0 = NativeTrainStep(m0, ComputeLoss(m0), nt_max=64)
+            s0._enqueue_fb(s0.load_inputs(x, t))
+            ref = m0.flat_grads.clone()
+            dist.all_reduce(ref)
+            # the overlapped schedule: segments of the backward list, one bucket launched behind each, waited for once
+            m = _model()
+            parallel.broadcast_parameters(m)
+            hook = parallel.GradAllReduce(world)
+            step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=False, grad_hook=hook, overlap=True)
+            p0 = m.flat_params.clone()
+            step.step(x, t)
+            cuts = m._engines[next(iter(m._engines))]._cuts
+            gerr = float((m.flat_grads - ref).abs().max() / ref.abs().max())
+            mine = m.flat_params.clone()
+            others = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(others, mine)
+            same = all(torch.equal(o, others[0]) for o in others)
+            moved = float((mine - p0).abs().max())
+            q.put((rank, len(cuts), gerr, same, moved, None))
+            dist.barrier()
+            dist.destroy_process_group()
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, 0.0, False, 0.0, traceback.format_exc()[-2000:]))
+        raise
+
+
+def test_dp_overlapped_schedule_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    from emu.harness import emu_lib_path
+    emu_lib_path()                                     # build once, before the ranks race for it
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, ncuts, gerr, same, moved, err in res:
+        assert err is None, err
+        assert ncuts == 2
+        # overlapped == plain up to the order of the f32 atomic adds of two separate backward passes (bf16 operands; a bucket
+        # exchanged before its gradients were final, a wrong range or a missing wait would be O(1))
+        assert gerr < 1e-4, gerr
+        assert same, "parameters differ across ranks after the optimizer"
+        assert moved > 0
+    assert all(p.exitcode == 0 for p in procs)

@@ -392,17 +392,18 @@ static bool bp_eligible(const BwdPwParams& P, int dtype) {
     if (P.N != P.C || !(P.C == 48 || P.C == 96 || P.C == 192)) return false;
     if (P.M <= 0 || P.nseg < 1 || P.nseg > 2 || P.act != Y5M_ACT_SILU) return false;
     if (P.ldy % 8 != 0 || P.ldx % 8 != 0 || !P.y || !P.x) return false;
+    if (P.ldy < P.N || P.ldx < P.C) return false;                                // a pixel row holds at least the channels read
     if ((reinterpret_cast<uintptr_t>(P.y) | reinterpret_cast<uintptr_t>(P.x)) & 15) return false;
     if (P.dx) {
         if (!P.wd || P.Kp < (P.N + 7) / 8 * 8 || P.Kp % 8 != 0) return false;     // the 16-byte pieces with k0 < N stay inside a row
-        if (P.lddx % 8 != 0 || (reinterpret_cast<uintptr_t>(P.dx) & 15) != 0) return false;
-        if (P.res && (P.ldres % 4 != 0 || (reinterpret_cast<uintptr_t>(P.res) & 7) != 0)) return false;
+        if (P.lddx % 8 != 0 || P.lddx < P.C || (reinterpret_cast<uintptr_t>(P.dx) & 15) != 0) return false;
+        if (P.res && (P.ldres < P.C || P.ldres % 4 != 0 || (reinterpret_cast<uintptr_t>(P.res) & 7) != 0)) return false;
     }
     int covered = 0;
     for (int s = 0; s < P.nseg; ++s) {
         const auto& S = P.seg[s];
         if (S.c0 != covered || S.cn <= 0 || S.cn % 16 != 0 || !S.acc || !S.scale || !S.shift || !S.mean || !S.invstd || !S.dw) return false;
-        if (!S.dz || S.lddz % 8 != 0 || (reinterpret_cast<uintptr_t>(S.dz) & 15) != 0) return false;
+        if (!S.dz || S.lddz % 8 != 0 || S.lddz < S.cn || (reinterpret_cast<uintptr_t>(S.dz) & 15) != 0) return false;
         covered += S.cn;
     }
     return covered == P.N && P.lddw >= P.C;

@@ -110,7 +110,6 @@ class Engine:
         self._pending = {}
         import os
         self.overlap = os.environ.get("Y5M_OVERLAP", "1") != "0"   # wgrad on a forked stream (see _side_op)
-        self.ablate = set(x for x in os.environ.get("Y5M_ABLATE", "").split(",") if x)
         # dy scratch ring: the main stream only waits for the weight gradient that used a slot nslots layers ago,
         # so it runs ahead of the side stream instead of ping-ponging with it (each cross-stream wait costs
         # ~10-15 us of dependency latency inside a hipGraph); 0.63 GB per slot at B=64 / 640^2; with the weight gradient forked after the data gradient 3 slots measure
@@ -317,12 +316,11 @@ class Engine:
                                    th, kw0, 2, tw, _lib.ptr(wd), wd.shape[0], wd.shape[1], 0, dt)
 
         def backward(lay=lay, P=P, need_dx=need_dx):
-            if (self.fused_pw and self.fuse_b and need_dx and lay.kk == 1 and lay.ss == 1 and lay.res is None
-                    and not lay.stem and not (self.ablate & {"wgrad_pw", "wgrad_3x3"})):
+            if self.fused_pw and self.fuse_b and need_dx and lay.kk == 1 and lay.ss == 1 and lay.res is None and not lay.stem:
                 fops = self._bwd_pw_ops(lay.x, lay.y_ptr, lay.y_ld, lay.wd[0][0], [(lay, P)], lay.M, lay.cout)
                 if fops is not None:
                     return fops
-            if lay.stem and self.fused_stem and self.fuse_b and not need_dx and not self.ablate:
+            if lay.stem and self.fused_stem and self.fuse_b and not need_dx:
                 fops = self._bwd_stem_ops(lay, P)
                 if fops is not None:
                     return fops
@@ -468,20 +466,23 @@ class Engine:
             sg.scale, sg.shift, sg.mean, sg.invstd = (bn[k].data_ptr() for k in range(4))
             sg.dgamma, sg.dbeta, sg.dw = P["gg"].data_ptr(), P["gb"].data_ptr(), P["gw"].data_ptr()
             c0 += lay.cout
+        # the launch's accumulation mode and lazy residual source are part of what the library checks: fill them in from a
+        # PEEK at the plan-time flags, and commit the bookkeeping only once the launch is known to qualify
+        acc = 1 if x.gw else 0
+        lazy = x.lazy
+        if lazy is not None:
+            assert acc == 1
+            a.res, a.ldres = lazy.ptr, lazy.ld
+        a.accumulate = acc
         if M < self.fused_pw_min_m or not L.y5m_bwd_pw_eligible(ctypes.byref(a), dt):
             return None
         ops = []
         for lay, P in segs:
             ops.extend(self._flush_lazy(lay.z))
-        acc = 1 if x.gw else 0
         x.gw = True
         for c in x.children:
             c.gw = True
-        lazy, x.lazy = x.lazy, None
-        if lazy is not None:
-            assert acc == 1
-            a.res, a.ldres = lazy.ptr, lazy.ld
-        a.accumulate = acc
+        x.lazy = None
         for i, (lay, P) in enumerate(segs):
             sg = a.seg[i]
             def reduce(lay=lay, sg=sg):
@@ -712,7 +713,7 @@ class Engine:
                            ctypes.c_void_p(wd.data_ptr() + lay.off * esz), wd.shape[0], cols, 0, dt, wd.shape[1])
 
         def backward():
-            if self.fused_pw and self.fuse_b and need_dx and not (self.ablate & {"wgrad_pw", "wgrad_3x3"}):
+            if self.fused_pw and self.fuse_b and need_dx:
                 fops = self._bwd_pw_ops(x, y2.data_ptr(), N2, wd, halves, M, N2)
                 if fops is not None:
                     return fops
@@ -854,7 +855,7 @@ class Engine:
                     else:
                         _lib.check(L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch),
                                                         ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack")
-                ops.append((pack, ()))
+                ops.append((_kind(pack, "head_pack"), ()))
                 wa = WgradArgs()
                 wa.zeros = _lib.zero_page(self.dev).data_ptr()
                 wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
@@ -953,13 +954,16 @@ class Engine:
             self.bwd.append((_kind(lambda: self.gw.zero_(), "fill"), ()))
             self.bwd.append((_kind(lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, "fill"), ()))
             # bwd_marks[i] = (op index after which unit i's parameter gradients are final, unit name,
-            # device address of its weight gradient inside the flat buffer) -- in backward order
-            self.bwd_marks = []
+            # device address of its weight gradient inside the flat buffer) -- in backward order. The marks are taken from the
+            # FINAL order of the list (after the reorder below): a unit's mark is one past the last of ITS OWN ops, wherever
+            # the reorder put them, so a cut (grad_cuts) can never fall in front of a launch that still writes the unit's
+            # gradients.
+            units = []                                     # (ops of the unit, [(name, address)])
             for mk in reversed(self._bwd_stack):
-                n0 = len(self._grad_done)
+                n0, i0 = len(self._grad_done), len(self.bwd)
                 self.bwd.extend(mk())
-                for name, addr in self._grad_done[n0:]:
-                    self.bwd_marks.append((len(self.bwd), name, addr))
+                if len(self._grad_done) > n0:
+                    units.append((self.bwd[i0:], self._grad_done[n0:]))
             for sl in range(self.nslots):
                 self.bwd.append((self._join_op(sl, final=True), ()))
             if os.environ.get("Y5M_WGRAD_AFTER_DGRAD", "1") == "1":
@@ -981,6 +985,37 @@ class Engine:
                         out.append(op)
                         i += 1
                 self.bwd = out
+            pos = {id(op[0]): i for i, op in enumerate(self.bwd)}
+            assert len(pos) == len(self.bwd), "launch closures must be distinct objects"
+            self.bwd_marks = []
+            for ops, done in units:
+                k = 1 + max(pos[id(op[0])] for op in ops)
+                for name, addr in done:
+                    self.bwd_marks.append((k, name, addr))
+            self._check_grad_writers(units, pos)
+
+    # kinds of launch-list entries that write parameter gradients (weights, gamma, beta, head bias)
+    _GRAD_WRITER_KINDS = ("wgrad", "bwd_pw", "bwd_stem", "unpack", "bn_bwd(reduce + apply)", "bn_reduce", "head_pack")
+
+    def _check_grad_writers(self, units, pos):
+        """plan-time invariant of the overlapped gradient exchange: every launch that writes a unit's parameter gradients sits
+        in front of that unit's mark, and the marks do not decrease along the backward order (a bucket is exchanged after the
+        cut that follows its last unit)."""
+        marks = {}
+        for k, name, _ in self.bwd_marks:
+            marks[name] = k
+        last = 0
+        for ops, done in units:
+            k = marks[done[0][0]]
+            assert all(marks[name] == k for name, _ in done)
+            assert k >= last, ("unit marks must not decrease", done[0][0], k, last)
+            last = k
+            for op in ops:
+                if getattr(op[0], "kind", None) in self._GRAD_WRITER_KINDS:
+                    assert pos[id(op[0])] < k, ("gradient writer behind its unit's mark", done[0][0], op[0].kind)
+        n_writers = sum(1 for op in self.bwd if getattr(op[0], "kind", None) in self._GRAD_WRITER_KINDS)
+        n_in_units = sum(1 for ops, _ in units for op in ops if getattr(op[0], "kind", None) in self._GRAD_WRITER_KINDS)
+        assert n_writers == n_in_units, ("a gradient-writing launch belongs to no unit", n_writers, n_in_units)
 
     # ------------------------------------------------------------------ side-stream overlap (backward)
     def _next_slot(self):
@@ -996,12 +1031,6 @@ class Engine:
         """Run `fns` on the side stream, ordered after everything enqueued so far on the current stream
         (fork). The completion event is kept per dy-buffer slot for the matching join. Inside a captured
         hipGraph this becomes a parallel branch. Y5M_OVERLAP=0 runs them inline."""
-        if wa is not None and self.ablate:
-            # Y5M_ABLATE (TIMING ONLY, gradients WRONG; `joins`: see _join_op): drop weight-gradient launches by class -- parameters then only see weight
-            # decay, the activations / gradients flowing through the step keep their values (tools/ab_step.sh)
-            taps = wa.th * wa.tw
-            if ("wgrad_pw" in self.ablate and taps == 1) or ("wgrad_3x3" in self.ablate and taps > 1):
-                fns = []
         def run():
             if not self.overlap:                    # (read at RUN time: a capture may switch the fork off, NativeTrainStep._capture)
                 for f in fns:
@@ -1032,7 +1061,7 @@ class Engine:
     def _join_op(self, slot, final=False):
         def run():
             ev = self._pending.pop(slot, None)
-            if ev is not None and (final or "joins" not in self.ablate):     # Y5M_ABLATE=joins (TIMING ONLY: dy slots race)
+            if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
         run.kind = "join"
         return run

@@ -320,13 +320,18 @@ class YOLOV5m(nn.Module):
             import gc
             gc.collect()
             m0 = torch.cuda.memory_allocated(dev)
+            eng, retry = None, False
             try:
                 eng = Engine(self, B, H, W, dtype=dt, training=self.training)
             except torch.OutOfMemoryError:
-                # the estimate was too small (or there was nothing to estimate from): drop EVERY resident plan and retry once
-                while self._engines:
+                # the estimate was too small (or there was nothing to estimate from). Only NOTE it here: while this handler
+                # runs, the exception's traceback keeps the frames of the failed Engine.__init__ -- and with them the partly
+                # built plan's tens of GB -- alive, so nothing freed in here would make room for the retry
+                retry = True
+            if retry:
+                while self._engines:                      # drop EVERY resident plan, then retry once
                     self._engines.pop(next(iter(self._engines))).release()
-                gc.collect()
+                gc.collect()                              # (the dead partial plan is a reference cycle through its launch closures)
                 torch.cuda.empty_cache()
                 m0 = torch.cuda.memory_allocated(dev)
                 eng = Engine(self, B, H, W, dtype=dt, training=self.training)

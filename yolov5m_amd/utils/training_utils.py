@@ -32,6 +32,7 @@ from .. import _lib, config
 # exist further plans are captured LINEARLY (weight gradients inline, ~5 % slower per step) so that a long multi_scale run
 # which keeps evicting and re-capturing its largest plans cannot leak without bound. NOTES.md has the hunt.
 _KEPT_GRAPHS = []
+_WARNED_LINEAR = False
 
 
 def _keep_forever(g):
@@ -42,7 +43,16 @@ def _keep_forever(g):
 
 
 def _forked_capture_allowed():
-    return len(_KEPT_GRAPHS) < int(os.environ.get("Y5M_GRAPH_KEEP_MAX", "64"))
+    """False once Y5M_GRAPH_KEEP_MAX forked graphs are being kept alive: further plans are captured linearly. Says so once --
+    a long multi_scale / data-parallel run that reaches the cap runs its re-captured sizes ~5 % slower from then on."""
+    global _WARNED_LINEAR
+    ok = len(_KEPT_GRAPHS) < int(os.environ.get("Y5M_GRAPH_KEEP_MAX", "64"))
+    if not ok and not _WARNED_LINEAR:
+        _WARNED_LINEAR = True
+        import warnings
+        warnings.warn(f"{len(_KEPT_GRAPHS)} captured graphs with forked branches are being kept alive (Y5M_GRAPH_KEEP_MAX): "
+                      "plans captured from now on run their weight gradients inline (about 5 % slower per step)")
+    return ok
 
 
 def multi_scale(img, target_shape, max_stride):
@@ -250,9 +260,9 @@ class NativeTrainStep:
         back to back; grad_hook (the RCCL all-reduce) runs between them on the same stream."""
         eng = self.load_inputs(images, targets)
         self.model._nbt += 1
+        self._check_hyper()                              # (before the accumulation branch too: its optimizer graph bakes lr in)
         if self.accumulate > 1:
             return self._step_accumulate(eng)
-        self._check_hyper()
         if self.overlap and hasattr(self.grad_hook, "launch") and getattr(self.grad_hook, "active", True):
             return self._step_overlapped(eng)
         if not self.use_graph:
@@ -323,9 +333,11 @@ class NativeTrainStep:
                 gs = []
                 for i in range(len(ks)):
                     g = torch.cuda.CUDAGraph()
+                    if forked:
+                        _keep_forever(g)                 # (before the capture: a capture that fails half-way is kept too)
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         seg(i)
-                    gs.append(_keep_forever(g) if forked else g)
+                    gs.append(g)
                 if self._opt_graph is None:
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, capture_error_mode="thread_local"):
@@ -381,6 +393,8 @@ class NativeTrainStep:
             eng.overlap = forked
             # thread_local: a RCCL watchdog / other thread touching the HIP runtime must not abort the capture
             g1 = torch.cuda.CUDAGraph()
+            if forked:
+                _keep_forever(g1)                        # (before the capture: a capture that fails half-way is kept too)
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 enqueue()
             if self._opt_graph is None:
@@ -388,7 +402,7 @@ class NativeTrainStep:
                 with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._optimizer()
                 self._opt_graph = g2
-            self._fb_graphs[eng.key] = (eng, _keep_forever(g1) if forked else g1, "whole")
+            self._fb_graphs[eng.key] = (eng, g1, "whole")
         except Exception as e:                           # capture is an optimisation, never a requirement
             import warnings
             warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly")
@@ -425,6 +439,7 @@ class NativeTrainStep:
         """optimizer step on whatever has been accumulated (reference: `idx == nb-1`, the epoch's last batch)"""
         if self.accumulate <= 1 or self._micro == 0:
             return
+        self._check_hyper()
         if self.grad_hook is not None:
             self.grad_hook(self.gacc)
         if self.use_graph and self._opt_graph is not None:
