@@ -87,6 +87,21 @@ def test_gradients_behind_a_cut_are_final(min_m, monkeypatch):
         assert float(flat[:lo2].abs().max()) > 0                      # (the last segment did write its own part)
 
 
+def test_per_layer_backward_helper_of_the_full_size_gpu_test(monkeypatch):
+    """tests/test_gpu_model.py::test_bf16_per_layer_backward_full_size_default_dispatch checks one layer per shape class at
+    B = 64 @ 640x640 on the GPU; here its helper runs at 2 x 64 x 64 on the CPU executor with every eligible 1x1 CBL on the
+    fused pointwise kernel, so that the selection logic and the layer-local restatement are themselves tested on this machine"""
+    monkeypatch.setenv("Y5M_BWD_PW_MIN_M", "0")
+    from emu.harness import emulated
+    import test_gpu_model as T
+    monkeypatch.setattr(T, "DEV", "cpu")
+    with emulated():
+        worst, checked_dx, names, kinds = T._per_layer_backward(2, 64, one_per_shape=True)
+    assert kinds.count("bwd_pw") >= 10 and kinds.count("bwd_stem") == 1
+    assert checked_dx >= 8 and max(worst.values()) <= 2e-2
+    assert any(n.startswith("wgrad_rows_kernel") for n in names) and any(n.startswith("conv_halo_kernel<6,3>") for n in names), names
+
+
 def test_plan_cache_retries_after_oom_outside_the_handler(monkeypatch):
     """the retry after an out-of-memory plan build must run AFTER the except block (the traceback keeps the failed
     plan alive inside it), with every resident plan released first"""

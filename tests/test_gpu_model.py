@@ -296,21 +296,15 @@ def _layer_nchw(t, ld, off, B, H, W, C):
     return v.permute(0, 3, 1, 2).float().cpu().contiguous()
 
 
-def test_bf16_per_layer_backward_on_engine_operands():
-    """Element-wise bf16 gradient parity INSIDE the model (B = 16 @ 320x320, the benchmark's kernels as the engine
-    dispatches them: merged C3 pairs, lazy residual gradients, stride-2 multi-launch data gradients, forked weight
-    gradients, accumulator-row BatchNorm). After one native forward + loss + backward, every CBL is checked BY ITSELF on
-    the operands the engine stored for it -- its input x (bf16), raw conv output y (bf16), output gradient dz (bf16) and
-    the batch statistics it used -- against a torch-f32 CPU restatement of that one layer's backward:
-        dgamma, dbeta   (BatchNorm + SiLU backward reduction)
-        dW              (weight gradient of dy rounded to bf16, as the engine stores dy)
-        dx              (data gradient; only where x has exactly ONE consumer, so that x.grad IS this layer's dx)
-    to 2e-2 of the tensor's max (the per-kernel bf16 tolerance of tests/test_gpu_conv.py). End-to-end bf16 comparisons
-    are chaotic in this network (test_bf16_train_step_vs_quantisation_aware_oracle); layer-local ones are not."""
+def _per_layer_backward(B, S, one_per_shape=False):
+    """one native bf16 forward + loss + backward at (B, S); every CBL (or, with one_per_shape, the FIRST layer of every distinct
+    (fused?, kernel size, stride, channels, output size, merged pair, residual) class) checked by itself on the operands the
+    engine stored for it. Returns (worst errors, number of dx-checked layers, kernel names seen, launch kinds of the plan)."""
+    import ctypes
+    from yolov5m_amd import _lib
     from yolov5m_amd.ultralytics_loss import ComputeLoss
     from yolov5m_amd.utils.training_utils import NativeTrainStep
     import torch.nn.functional as F
-    B, S = 16, 320
     m = _model("bf16"); m.train()
     step = NativeTrainStep(m, ComputeLoss(m), nt_max=B * 8, use_graph=False)
     x = synth_images(B, S, S, seed="img/rank0").to(DEV)
@@ -320,7 +314,21 @@ def test_bf16_per_layer_backward_on_engine_operands():
     torch.cuda.synchronize()
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     checked_dx, worst, pair_dx = 0, {}, {}
+    L, buf, names, seen = _lib.lib(), ctypes.create_string_buffer(192), set(), set()
     for lay in eng.layers:
+        fused = not hasattr(lay, "wgrad_args") and not hasattr(lay, "off")
+        root_ = lay.x.parent if lay.x.parent is not None else lay.x
+        dx_checkable = lay.x.grad is not None and root_.n_cons == 1 and lay.x.parent is None
+        key = (fused, lay.k, lay.s, lay.x.C, lay.cout, lay.Ho, lay.Wo, hasattr(lay, "off"), lay.res is not None, dx_checkable)
+        if one_per_shape and key in seen and not (hasattr(lay, "off") and id(lay.x) in pair_dx):
+            continue
+        seen.add(key)
+        if hasattr(lay, "wgrad_args"):
+            _lib.check(L.y5m_wgrad_kernel_name(ctypes.byref(lay.wgrad_args), eng.dtype, buf, 192), "kernel_name")
+            names.add(buf.value.decode())
+        for a_ in getattr(lay, "dgrad_args", []):
+            _lib.check(L.y5m_conv_kernel_name(ctypes.byref(a_), eng.dtype, buf, 192), "kernel_name")
+            names.add(buf.value.decode())
         P = m.pslices[lay.name]
         ybuf, yoff, yld = lay.y_view
         Ho, Wo, co = lay.Ho, lay.Wo, lay.cout
@@ -367,8 +375,40 @@ def test_bf16_per_layer_backward_on_engine_operands():
         for kq, v in e.items():
             assert v <= 2e-2, (lay.name, kq, v)
             worst[kq] = max(worst.get(kq, 0.0), v)
+    assert not pair_dx
+    kinds = [getattr(op[0], "kind", None) for op in eng.bwd]
+    return worst, checked_dx, names, kinds
+
+
+def test_bf16_per_layer_backward_on_engine_operands():
+    """Element-wise bf16 gradient parity INSIDE the model (B = 16 @ 320x320, the benchmark's kernels as the engine
+    dispatches them: merged C3 pairs, lazy residual gradients, stride-2 multi-launch data gradients, forked weight
+    gradients, accumulator-row BatchNorm). After one native forward + loss + backward, every CBL is checked BY ITSELF on
+    the operands the engine stored for it -- its input x (bf16), raw conv output y (bf16), output gradient dz (bf16) and
+    the batch statistics it used -- against a torch-f32 CPU restatement of that one layer's backward:
+        dgamma, dbeta   (BatchNorm + SiLU backward reduction)
+        dW              (weight gradient of dy rounded to bf16, as the engine stores dy)
+        dx              (data gradient; only where x has exactly ONE consumer, so that x.grad IS this layer's dx)
+    to 2e-2 of the tensor's max (the per-kernel bf16 tolerance of tests/test_gpu_conv.py). End-to-end bf16 comparisons
+    are chaotic in this network (test_bf16_train_step_vs_quantisation_aware_oracle); layer-local ones are not."""
+    worst, checked_dx, names, kinds = _per_layer_backward(16, 320)
     print("per-layer bf16 backward: worst", {k: f"{v:.2e}" for k, v in worst.items()}, "dx-checked layers", checked_dx)
-    assert checked_dx >= 20 and not pair_dx
+    assert checked_dx >= 20
+
+
+def test_bf16_per_layer_backward_full_size_default_dispatch():
+    """The same layer-local bf16 gradient check at the BENCHMARK's size (B = 64 @ 640x640) with the default dispatch, where the
+    kernels that only run at full size are the ones under test: bwd_pw_kernel (>= 200 000 pixels: the 160x160 / 80x80 1x1 CBLs
+    and merged C3 pairs), bwd_stem_kernel, both wgrad_rows_kernel shapes (48 input channels), the split pixel range of the
+    384 -> 768 stride-2 weight gradient and the halo-patch data gradients. One layer per distinct shape class (the torch-f32
+    CPU restatement of a 160x160 layer's gradients at B = 64 is tens of GFLOP) -- reference model.py:12-28."""
+    worst, checked_dx, names, kinds = _per_layer_backward(64, 640, one_per_shape=True)
+    print("per-layer bf16 backward at B=64 @ 640: worst", {k: f"{v:.2e}" for k, v in worst.items()}, "dx-checked layers", checked_dx,
+          "kernels", sorted(names))
+    assert kinds.count("bwd_pw") >= 10 and kinds.count("bwd_stem") == 1, (kinds.count("bwd_pw"), kinds.count("bwd_stem"))
+    assert any(n.startswith("wgrad_rows_kernel<2,2,2>") for n in names) and any(n.startswith("wgrad_rows_kernel<1,4,1>") for n in names), names
+    assert any(n.startswith("conv_halo_kernel<6,3>") for n in names) and any(n.startswith("conv_igemm_multi") or "igemm" in n for n in names), names
+    assert checked_dx >= 8
 
 
 def test_submodule_forward_matches_torch():
