@@ -61,10 +61,13 @@ def pmc_traffic(kernel=None):
         return None, f"unreadable {files[-1]}: {e}"
 
 
-def cpu_baseline(B=4, size=640, steps=3):
+def cpu_baseline(B=4, size=640, steps=3, world=1):
     """CPU leg: the oracle restatement of the reference path (model fwd, ComputeLoss, autograd bwd,
-    clip, Adam) on the host cores. kind = "port". Bounded: B=4, 1 warm-up + `steps` timed steps."""
+    clip, Adam) on the host cores. kind = "port". Bounded: B=4, 1 warm-up + `steps` timed steps.
+    world > 1: torch.distributed.run starts every rank with OMP_NUM_THREADS=1; rank 0 takes its share of the cores back."""
     from oracle import loss_ref, model_ref
+    if world > 1:
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     from yolov5m_amd.utils.synth import synth_state_dict, synth_images, synth_labels
     torch.manual_seed(0)
     sd = synth_state_dict()
@@ -277,6 +280,25 @@ def main():
     dev = f"cuda:{local}"
     _lib.check(_lib.lib().y5m_device_ok(), "y5m_device_ok")
 
+    # who is running: one line per rank (device, PCI bus id, RCCL version, CU cap of the persistent kernels) gathered on rank 0;
+    # with RCCL every rank must sit on its OWN device
+    props = torch.cuda.get_device_properties(local)
+    ident = {"rank": rank, "device_index": local, "name": props.name, "gcn_arch": getattr(props, "gcnArchName", None),
+             "pci_bus_id": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}",
+             "uuid": str(getattr(props, "uuid", "")), "persistent_cus": int(_lib.lib().y5m_persistent_cu_count())}
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if backend == "nccl":
+            keys = {(d["uuid"], d["pci_bus_id"], d["device_index"]) for d in idents}
+            if len(keys) != world:
+                raise SystemExit(f"bench.py: {world} RCCL ranks on {len(keys)} distinct device(s): {idents}")
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl_version = None
+
     B, S = args.batch, args.size
     torch.manual_seed(0)                                   # identical random init on every rank
     model = YOLOV5m(first_out=config.FIRST_OUT, nc=80, anchors=config.ANCHORS,
@@ -331,6 +353,24 @@ def main():
                 b["ms"] = round(ms_, 3)
             xstats["allreduce_exposed_ms"] = round(float(v[nb]), 3)
 
+    # the same workload with the PLAIN exchange (one all-reduce after the backward pass), 2 warm-up + 5 timed steps in this
+    # same invocation, so that an N-GPU record carries overlapped and plain step times side by side
+    plain = None
+    if world > 1 and not args.no_overlap:
+        hook2 = parallel.GradAllReduce(world, timing=False)
+        step2 = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook2, overlap=False)
+        for _ in range(2):
+            step2.step(images, targets)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step2.step(images, targets)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        plain = {"steps": 5, "ms_per_step": round(float(tp[0]) / 5 * 1e3, 3)}
+        del step2
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -340,6 +380,7 @@ def main():
     out = {
         "metric": "images/sec (train step, 640x640)", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "dist_backend": backend,
+        "rccl_version": rccl_version, "ranks": idents,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"YOLOv5m full train step (fwd + ComputeLoss + bwd + clip + Adam), batch {B}/GPU @ "
@@ -353,7 +394,10 @@ def main():
                                    + ("one message after the backward pass" if args.no_overlap else
                                       "bucketed in backward order and overlapped with the backward pass (one captured "
                                       "graph per segment; buckets issued from a communication stream)"),
-                           "last_step_max_over_ranks": xstats}
+                           "last_step_max_over_ranks": xstats,
+                           # (what the exposed time should be on xGMI)
+                           "plain_exchange_same_run": plain,
+                           "overlap_gain_ms_per_step": round(plain["ms_per_step"] - ms, 3) if plain else None}
     if not args.no_roofline:
         fams = {}
         cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0], "fused_pw_bwd": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
@@ -465,8 +509,9 @@ def main():
         model._engines = {}
         torch.cuda.empty_cache()
         out["detect"] = detect_leg(dev, model)
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    if not args.no_cpu_baseline:
+        # (rank 0's host cores; with N > 1 the other ranks idle at the final barrier meanwhile)
+        out["cpu_baseline"] = cpu_baseline(world=world)
     print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -43,6 +43,10 @@ const char* y5m_version(void);
 const char* y5m_last_error(void);
 /* runtime probe used by the Python side to fail loudly when no gfx950 device is usable */
 int y5m_device_ok(void);
+/* workgroups a persistent (one-per-CU) launch uses: the device's CU count, capped by the environment variable
+ * Y5M_PERSIST_CUS (read once per process; yolov5m_amd/parallel.py sets 240 for data-parallel runs so that the collective's
+ * kernels find free CUs). New entry point (the reference has no multi-GPU path). */
+int y5m_persistent_cu_count(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Detect path

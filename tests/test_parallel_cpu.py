@@ -27,6 +27,10 @@ def _worker(rank, world, port, q):
                       LOCAL_RANK=str(rank))
     r, l, w = parallel.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
+    # data-parallel runs cap the persistent (one-workgroup-per-CU) kernels at 240 CUs: the default is set by init_from_env
+    # before the library reads it, and the library reports what it will use (256 CUs assumed where no device answers)
+    from yolov5m_amd import _lib
+    assert os.environ.get("Y5M_PERSIST_CUS") == "240" and _lib.lib().y5m_persistent_cu_count() == 240
     n = 100003
     g = torch.Generator().manual_seed(1234 + rank)
     flat = torch.rand(n, generator=g)

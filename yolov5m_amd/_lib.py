@@ -99,6 +99,7 @@ _SIGS = {
     "y5m_version": (ctypes.c_char_p, []),
     "y5m_last_error": (ctypes.c_char_p, []),
     "y5m_device_ok": (c_int, []),
+    "y5m_persistent_cu_count": (c_int, []),
     "y5m_decode_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p,
                                  c_int64, c_int64, c_void_p]),
     "y5m_decode_targets_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64,

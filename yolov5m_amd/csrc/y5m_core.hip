@@ -44,6 +44,9 @@ int y5m_fill32(void* p, uint32_t v, size_t n_words, hipStream_t st) {
 extern "C" const char* y5m_version(void) { return "y5m-gfx950 0.1"; }
 extern "C" const char* y5m_last_error(void) { return g_err; }
 
+// workgroups a persistent (one per CU) launch uses: the device's CU count capped by Y5M_PERSIST_CUS (y5m_common.h)
+extern "C" int y5m_persistent_cu_count(void) { return y5m_persistent_cus(); }
+
 extern "C" int y5m_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
