@@ -441,6 +441,7 @@ def test_submodule_forward_matches_torch():
 
     def close(a, b, tol=1e-4):
         assert a.shape == b.shape
+        a = a.detach()
         assert float((a.cpu() - b).abs().max()) <= tol * float(b.abs().max()), float((a.cpu() - b).abs().max() / b.abs().max())
 
     for train in (False, True):
@@ -468,6 +469,98 @@ def test_submodule_forward_matches_torch():
     for i in range(3):
         y = F.conv2d(xs[i], ref[f"head.out_convs.{i}.weight"], ref[f"head.out_convs.{i}.bias"])
         close(got[i], y.view(2, 3, 85, y.shape[2], y.shape[3]).permute(0, 1, 3, 4, 2).contiguous())
+
+
+def test_submodule_backward_matches_torch():
+    """The sub-modules are autograd-capable like the reference's (model.py:26, :49, :90, :106, :165): gradients of a scalar
+    function of `model.backbone[i](x)` / `model.head(xs)` wrt the INPUT and every PARAMETER of the sub-module, f32 parity
+    mode, train mode (batch statistics) -- against the same layers in plain torch autograd on the CPU. Covers a stride-2 CBL,
+    the stem (3 input channels, 6x6 / stride 2), a backbone C3 (residual bottlenecks), a neck C3, SPPF (the pool cascade's
+    backward) and the head convs (255 channels + bias); eval mode on one CBL (running statistics as constants)."""
+    import torch.nn.functional as F
+    m = _model("f32")
+    sd = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+
+    def leaf(name):
+        t = sd[name].clone().requires_grad_(True)
+        used[name] = t
+        return t
+
+    def cbl(name, x, train=True):
+        w = leaf(f"{name}.cbl.0.weight")
+        k = w.shape[-1]
+        s, p = {"backbone.0": (2, 2), "backbone.1": (2, 1), "backbone.3": (2, 1), "neck.4": (2, 1)}.get(name, (1, k // 2))
+        y = F.conv2d(x, w, None, s, p)
+        z = F.batch_norm(y, sd[f"{name}.cbl.1.running_mean"].clone(), sd[f"{name}.cbl.1.running_var"].clone(),
+                         leaf(f"{name}.cbl.1.weight"), leaf(f"{name}.cbl.1.bias"), train, 0.03, 1e-3)
+        return F.silu(z)
+
+    def c3(name, x, depth, backbone):
+        t = cbl(f"{name}.c1", x)
+        for d in range(depth):
+            if backbone:
+                t = cbl(f"{name}.seq.{d}.c2", cbl(f"{name}.seq.{d}.c1", t)) + t
+            else:
+                t = cbl(f"{name}.seq.{d}.1", cbl(f"{name}.seq.{d}.0", t))
+        return cbl(f"{name}.c_out", torch.cat([t, cbl(f"{name}.c_skipped", x)], 1))
+
+    def sppf(name, x):
+        t = cbl(f"{name}.c1", x)
+        p1 = F.max_pool2d(t, 5, 1, 2); p2 = F.max_pool2d(p1, 5, 1, 2); p3 = F.max_pool2d(p2, 5, 1, 2)
+        return cbl(f"{name}.c_out", torch.cat([t, p1, p2, p3], 1))
+
+    def check(tag, module, prefix, ref_fn, x, tol, train=True):
+        nonlocal used
+        used = {}
+        module.train(train)
+        for p_ in module.parameters():
+            p_.grad = None
+        xr = x.clone().requires_grad_(True)
+        out_r = ref_fn(xr)
+        gsel = _rand_like(tuple(out_r.shape), 99)                      # a fixed random cotangent
+        (out_r * gsel).sum().backward()
+        xg = x.clone().to(DEV).requires_grad_(True)
+        out = module(xg)
+        assert out.requires_grad
+        (out * gsel.to(DEV)).sum().backward()
+
+        def close(a, b, what):
+            err = float((a.detach().float().cpu() - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+            assert err <= tol, (tag, what, err)
+        close(out, out_r.detach(), "forward")
+        close(xg.grad, xr.grad, "d input")
+        params = dict(module.named_parameters())
+        assert len(used) == len(params), (tag, sorted(used), sorted(params))
+        for name, t in used.items():
+            close(params[name[len(prefix) + 1:]].grad, t.grad, name)
+
+    used = {}
+    check("cbl s2", m.backbone[1], "backbone.1", lambda x: cbl("backbone.1", x), _rand_like((2, 48, 16, 24), 7), 2e-4)
+    check("stem", m.backbone[0], "backbone.0", lambda x: cbl("backbone.0", x), synth_images(2, 32, 64, seed="subb"), 2e-4)
+    check("c3 backbone", m.backbone[2], "backbone.2", lambda x: c3("backbone.2", x, 2, True), _rand_like((2, 96, 8, 12), 8), 2e-3)
+    check("c3 neck", m.neck[3], "neck.3", lambda x: c3("neck.3", x, 2, False), _rand_like((2, 384, 8, 12), 10), 2e-3)
+    check("sppf", m.backbone[9], "backbone.9", lambda x: sppf("backbone.9", x), _rand_like((2, 768, 6, 6), 9), 2e-3)
+    check("cbl eval", m.backbone[3], "backbone.3", lambda x: cbl("backbone.3", x, False), _rand_like((2, 96, 8, 12), 11), 2e-4,
+          train=False)
+    # heads: three inputs, one list output
+    m.train()
+    xs = [_rand_like((2, 192, 8, 12), 11), _rand_like((2, 384, 4, 6), 12), _rand_like((2, 768, 2, 3), 13)]
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    xg = [t.clone().to(DEV).requires_grad_(True) for t in xs]
+    for p_ in m.head.parameters():
+        p_.grad = None
+    got = m.head(xg)
+    for i in range(3):
+        w, b = sd[f"head.out_convs.{i}.weight"].clone().requires_grad_(True), sd[f"head.out_convs.{i}.bias"].clone().requires_grad_(True)
+        y = F.conv2d(xr[i], w, b)
+        o = y.view(2, 3, 85, y.shape[2], y.shape[3]).permute(0, 1, 3, 4, 2).contiguous()
+        gsel = _rand_like(tuple(o.shape), 100 + i)
+        (o * gsel).sum().backward()
+        (got[i] * gsel.to(DEV)).sum().backward()
+        for a, r, what in ((xg[i].grad, xr[i].grad, "dx"), (m.head.out_convs[i].weight.grad, w.grad, "dw"),
+                           (m.head.out_convs[i].bias.grad, b.grad, "db")):
+            err = float((a.detach().float().cpu() - r).abs().max()) / float(r.abs().max())
+            assert err <= 2e-4, ("head", i, what, err)
 
 
 def _rand_like(shape, seed):

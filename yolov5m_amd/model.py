@@ -6,11 +6,13 @@ names (481 state_dict keys) with PyTorch's default initialisation; t
 re-pointed into ONE flat f32 parameter buffer (and one flat gradient buffer) the first time the model
 runs on the GPU, which is what the fused optimizer and the RCCL gradient all-reduce operate on.
 YOLOV5m.forward is a single autograd Function around the native forward / backward plan (the hot path).
-The sub-modules' own forward() (reference model.py:26, :49, :90, :106, :165 -- `model.backbone[i](x)`) also executes,
-FORWARD ONLY: every CBL is a native conv (+ batch statistics) + BatchNorm + SiLU launch sequence through the op-level
-C-ABI wrappers (yolov5m_amd/ops.py: NCHW in / out with a layout conversion per call, `compute_dtype` "f32" unless set), the
-glue between CBLs (residual add, channel concat) is torch tensor arithmetic on the GPU, the SPPF pools are the native kernel.
-The result carries no autograd graph: gradients exist only through the whole model.
+The sub-modules' own forward() (reference model.py:26, :49, :90, :106, :165 -- `model.backbone[i](x)`) also executes, WITH
+autograd: every CBL is one autograd node (`_CBLFn`) whose forward is the native conv (+ batch statistics) + BatchNorm + SiLU
+launch sequence and whose backward is the native BatchNorm / SiLU backward, data gradient and weight gradient, through the
+op-level C-ABI wrappers (yolov5m_amd/ops.py: NCHW in / out with a layout conversion per call, `compute_dtype` "f32" unless
+set); the SPPF pool cascade (`_SppfPoolFn`) and the head convs (`_ConvBiasFn`) likewise. The glue between them (residual add,
+channel concat, the head's view / permute) is torch tensor arithmetic on the GPU, differentiated by torch. This is the
+module-level API surface, not the hot path: the whole model runs as ONE autograd node over the engine's plan (`_ModelFn`).
 """
 import os
 
@@ -33,31 +35,70 @@ class CBL(nn.Module):
     compute_dtype = "f32"        # sub-module execution: "f32" (parity) or "bf16"; per instance or on the class
 
     def forward(self, x):
-        """reference model.py:26-28, forward only (no autograd graph): train mode uses batch statistics and updates the
-        running ones (momentum 0.03, eps 1e-3), eval mode the folded running statistics"""
-        from . import ops
+        """reference model.py:26-28: train mode uses batch statistics and updates the running ones (momentum 0.03, eps 1e-3),
+        eval mode the running statistics; differentiable wrt the input and the parameters (one autograd node, `_CBLFn`)"""
         _lib.require_cuda(x)
         conv, bn = self.cbl[0], self.cbl[1]
+        return _CBLFn.apply(x.float(), conv.weight, bn.weight, bn.bias, self)
+
+
+class _CBLFn(torch.autograd.Function):
+    """conv + BatchNorm + SiLU of one CBL as ONE autograd node over the native op-level launches (reference model.py:12-28)"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, mod):
+        from . import ops
+        conv, bn = mod.cbl[0], mod.cbl[1]
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        ch = 8 if self.compute_dtype == "bf16" else 4
-        x = x.detach().float()
-        w = conv.weight.detach().float()
-        if x.shape[1] % ch:                                   # the stem's 3 input channels: zero channels up to a 16-byte piece
-            padc = ch - x.shape[1] % ch
-            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
-            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, padc))
-        with torch.no_grad():
-            if self.training:
-                _y, z, _sc, _sh, _mean, _invstd, rm, rv = ops.conv_forward_bn_fused(
-                    x, w, s, p, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                    self.compute_dtype)
-                bn.running_mean.copy_(rm)
-                bn.running_var.copy_(rv)
-                bn.num_batches_tracked += 1
-                return z
-            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
-            shift = bn.bias.detach().float() - bn.running_mean.float() * scale
-            return ops.conv_forward(x, w, s, p, self.compute_dtype, scale=scale, shift=shift, act=True)
+        dtype = mod.compute_dtype
+        ch = 8 if dtype == "bf16" else 4
+        cin = x.shape[1]
+        xd, wd = x.detach().float(), w.detach().float()
+        if cin % ch:                                          # the stem's 3 input channels: zero channels up to a 16-byte piece
+            padc = ch - cin % ch
+            xd = torch.nn.functional.pad(xd, (0, 0, 0, 0, 0, padc))
+            wd = torch.nn.functional.pad(wd, (0, 0, 0, 0, 0, padc))
+        ctx.geom = (k, s, p, dtype, cin, tuple(x.shape[2:]))
+        ctx.training = mod.training
+        if mod.training:
+            y, z, sc, sh, mean, invstd, rm, rv = ops.conv_forward_bn_fused(
+                xd, wd, s, p, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, dtype)
+            bn.running_mean.copy_(rm)
+            bn.running_var.copy_(rv)
+            bn.num_batches_tracked += 1
+        else:
+            invstd = 1.0 / torch.sqrt(bn.running_var.float() + bn.eps)
+            mean = bn.running_mean.float()
+            sc = gamma.detach().float() * invstd
+            sh = beta.detach().float() - mean * sc
+            need_y = any(ctx.needs_input_grad[:4])
+            y = ops.conv_forward(xd, wd, s, p, dtype) if need_y else None      # (raw conv output: only the backward reads it)
+            z = ops.bn_act(y, sc, sh, dtype) if need_y else ops.conv_forward(xd, wd, s, p, dtype, scale=sc, shift=sh, act=True)
+        ctx.save_for_backward(xd, wd, y, sc, sh, mean, invstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        from . import ops
+        xd, wd, y, sc, sh, mean, invstd = ctx.saved_tensors
+        k, s, p, dtype, cin, hw = ctx.geom
+        dz = dz.contiguous().float()
+        if ctx.training:
+            dy, dgamma, dbeta = ops.bn_silu_backward(dz, y, sc, sh, mean, invstd, dtype)
+        else:
+            # running statistics are constants: elementwise glue (the eval-mode backward is not a training path)
+            t = y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+            sg = torch.sigmoid(t)
+            dt = dz * (sg * (1 + t * (1 - sg)))
+            dy = dt * sc.view(1, -1, 1, 1)
+            dbeta = dt.sum((0, 2, 3))
+            dgamma = (dt * (y - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)).sum((0, 2, 3))
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_dgrad(dy, wd, hw, s, p, dtype)[:, :cin]
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(dy, xd, k, s, p, dtype)[:, :cin]
+        return dx, dw, dgamma, dbeta, None
 
 
 class Bottleneck(nn.Module):
@@ -105,10 +146,30 @@ class SPPF(nn.Module):
 
     def forward(self, x):
         """reference model.py:106-112: the three cascaded 5x5 max-pools are ONE native launch (y5m_sppf_pool)"""
-        from . import ops
         x = self.c1(x)
-        p1, p2, p3 = ops.sppf_pool(x, self.c1.compute_dtype)
+        p1, p2, p3 = _SppfPoolFn.apply(x, self.c1.compute_dtype)
         return self.c_out(torch.cat([x, p1, p2, p3], dim=1))
+
+
+class _SppfPoolFn(torch.autograd.Function):
+    """the three cascaded MaxPool2d(5, 1, 2) of SPPF (reference model.py:108-110) as one autograd node: forward
+    y5m_sppf_pool, backward three accumulating y5m_maxpool5_bwd launches"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        from . import ops
+        p1, p2, p3 = ops.sppf_pool(x.detach().float(), dtype)
+        ctx.save_for_backward(x.detach().float(), p1, p2)
+        ctx.dtype = dtype
+        return p1, p2, p3
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        from . import ops
+        x, p1, p2 = ctx.saved_tensors
+        z = torch.zeros_like(x)
+        g = [z] + [t.contiguous().float() if t is not None else z for t in (g1, g2, g3)]
+        return ops.sppf_pool_backward(x, p1, p2, g, ctx.dtype), None
 
 
 class HEADS(nn.Module):
@@ -130,22 +191,45 @@ class HEADS(nn.Module):
     compute_dtype = "f32"
 
     def forward(self, x):
-        """reference model.py:165-175: per scale a 1x1 conv with bias, viewed as (B, naxs, ny, nx, 5 + nc); forward only"""
-        from . import ops
+        """reference model.py:165-175: per scale a 1x1 conv with bias, viewed as (B, naxs, ny, nx, 5 + nc); differentiable
+        (`_ConvBiasFn`: native forward, data gradient and weight gradient)"""
         out = []
         for i in range(self.nl):
             conv = self.out_convs[i]
-            xi = x[i].detach().float()
-            _lib.require_cuda(xi)
-            with torch.no_grad():
-                ncout = conv.weight.shape[0]
-                padn = (-ncout) % 4                                            # 255 -> 256 output channels: 16-byte rows
-                w = torch.nn.functional.pad(conv.weight.detach().float(), (0, 0, 0, 0, 0, 0, 0, padn))
-                b = torch.nn.functional.pad(conv.bias.detach().float(), (0, padn))
-                y = ops.conv_forward(xi, w, 1, 0, self.compute_dtype, scale=torch.ones_like(b), shift=b, act=False)[:, :ncout]
+            _lib.require_cuda(x[i])
+            y = _ConvBiasFn.apply(x[i].float(), conv.weight, conv.bias, self.compute_dtype)
             bs, _, ny, nx = y.shape
             out.append(y.view(bs, self.naxs, 5 + self.nc, ny, nx).permute(0, 1, 3, 4, 2).contiguous())
         return out
+
+
+class _ConvBiasFn(torch.autograd.Function):
+    """1x1 conv + bias of a detection head (reference model.py:157-160, :170) over the native op-level launches"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dtype):
+        from . import ops
+        ncout = w.shape[0]
+        padn = (-ncout) % 4                                            # 255 -> 256 output channels: 16-byte rows
+        xd = x.detach().float()
+        wd = torch.nn.functional.pad(w.detach().float(), (0, 0, 0, 0, 0, 0, 0, padn))
+        bd = torch.nn.functional.pad(b.detach().float(), (0, padn))
+        y = ops.conv_forward(xd, wd, 1, 0, dtype, scale=torch.ones_like(bd), shift=bd, act=False)[:, :ncout]
+        ctx.save_for_backward(xd, wd)
+        ctx.meta = (dtype, ncout, padn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        xd, wd = ctx.saved_tensors
+        dtype, ncout, padn = ctx.meta
+        dy = dy.contiguous().float()
+        dyp = torch.nn.functional.pad(dy, (0, 0, 0, 0, 0, padn))
+        dx = ops.conv_dgrad(dyp, wd, tuple(xd.shape[2:]), 1, 0, dtype) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(dyp, xd, 1, 1, 0, dtype)[:ncout] if ctx.needs_input_grad[1] else None
+        db = dy.sum((0, 2, 3)) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
 
 
 class _ModelFn(torch.autograd.Function):

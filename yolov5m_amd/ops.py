@@ -347,3 +347,59 @@ def sppf_pool(x, dtype="f32"):
                                _lib.ptr(ws), wsb, dt, _lib.stream_ptr()), "y5m_sppf_pool")
     torch.cuda.synchronize()
     return tuple(from_nhwc(o) for o in outs)
+
+
+def bn_act(y, scale, shift, dtype="f32", act=True):
+    """z = act(y * scale + shift) per channel (y5m_bn_act): y (B,C,H,W), scale / shift (C,)"""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    _lib.require_cuda(y)
+    B, C, H, W = y.shape
+    yn = to_nhwc(y, tdt)
+    out = torch.zeros_like(yn)
+    sc, sh = scale.float().contiguous(), shift.float().contiguous()
+    _lib.check(L.y5m_bn_act(_lib.ptr(yn), C, _lib.ptr(sc), _lib.ptr(sh), None, 0, _lib.ptr(out), C, B * H * W, C,
+                            ACT_SILU if act else ACT_NONE, dt, _lib.stream_ptr()), "y5m_bn_act")
+    torch.cuda.synchronize()
+    return from_nhwc(out)
+
+
+def bn_silu_backward(dz, y, scale, shift, mean, invstd, dtype="f32"):
+    """autograd of z = silu(batch_norm(y)) with BATCH statistics wrt y, gamma, beta (y5m_bn_bwd_fused: reduce into f64
+    accumulator rows + apply): dz, y (B,C,H,W); scale = gamma * invstd, shift, mean, invstd (C,) as the forward produced them.
+    Returns dy (B,C,H,W) f32, dgamma, dbeta."""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    _lib.require_cuda(dz, y)
+    B, C, H, W = dz.shape
+    M = B * H * W
+    dzn, yn = to_nhwc(dz, tdt), to_nhwc(y, tdt)
+    dy = torch.zeros_like(dzn)
+    dg = torch.zeros(C, dtype=torch.float32, device=dz.device)
+    db = torch.zeros(C, dtype=torch.float32, device=dz.device)
+    acc = torch.zeros((L.y5m_bn_acc_slots(), 2, C), dtype=torch.float64, device=dz.device)
+    st = [t.float().contiguous() for t in (scale, shift, mean, invstd)]
+    _lib.check(L.y5m_bn_bwd_fused(_lib.ptr(dzn), C, _lib.ptr(yn), C, _lib.ptr(st[0]), _lib.ptr(st[1]), _lib.ptr(st[2]),
+                                  _lib.ptr(st[3]), M, C, ACT_SILU, _lib.ptr(dg), _lib.ptr(db), 0, _lib.ptr(dy), C,
+                                  acc.data_ptr(), dt, _lib.stream_ptr()), "y5m_bn_bwd_fused")
+    torch.cuda.synchronize()
+    return from_nhwc(dy), dg, db
+
+
+def sppf_pool_backward(x, p1, p2, g, dtype="f32"):
+    """autograd of the SPPF pool cascade p1 = pool(x), p2 = pool(p1), p3 = pool(p2) (reference model.py:108-110) wrt x:
+    g = (g_x, g_p1, g_p2, g_p3), the gradients arriving at the four concat slices (B,C,H,W). Three native launches
+    (y5m_maxpool5_bwd, accumulating): g_p2 += bwd(p2; g_p3), g_p1 += bwd(p1; g_p2), g_x += bwd(x; g_p1). Returns d(x)."""
+    L = _lib.lib()
+    dt, tdt, CH, BK = _DT[dtype]
+    _lib.require_cuda(x)
+    B, C, H, W = x.shape
+    src = [to_nhwc(t, tdt) for t in (x, p1, p2)]
+    gn = [to_nhwc(t, tdt) for t in g]
+    wsb = L.y5m_maxpool5_bwd_workspace_bytes(B, H, W, C)
+    ws = torch.zeros(max(wsb, 1), dtype=torch.uint8, device=x.device)
+    for lvl in (2, 1, 0):
+        _lib.check(L.y5m_maxpool5_bwd(_lib.ptr(src[lvl]), C, _lib.ptr(gn[lvl + 1]), C, B, H, W, C, _lib.ptr(gn[lvl]), C, 1,
+                                      _lib.ptr(ws), wsb, dt, _lib.stream_ptr()), "y5m_maxpool5_bwd")
+    torch.cuda.synchronize()
+    return from_nhwc(gn[0])
