@@ -9,11 +9,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "yolov5m_amd", "csrc")
-OUT_DIR = os.path.join(ROOT, "build", "emu")
+# Y5M_EMU_ASAN=1: the same library with AddressSanitizer on every global / heap access of the kernels (stack instrumentation off:
+# the fibers switch stacks behind the sanitizer's back). Load it in a python started with LD_PRELOAD=<asan runtime>
+# (tests/emu/asan_run.sh): an out-of-bounds read or write of a kernel on a tensor -- silent on the GPU -- aborts with a report.
+ASAN = os.environ.get("Y5M_EMU_ASAN") == "1"
+OUT_DIR = os.path.join(ROOT, "build", "emu_asan" if ASAN else "emu")
 LIB = os.path.join(OUT_DIR, "liby5m_emu.so")
 CXX = os.environ.get("Y5M_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-pthread",
          "-I", os.path.join(HERE, "include"), "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+if ASAN:
+    FLAGS += ["-fsanitize=address", "-shared-libasan", "-mllvm", "-asan-stack=0", "-fno-omit-frame-pointer", "-g1"]
 EXACT = {"y5m_detect.hip", "y5m_loss.hip"}          # same rule as csrc/Makefile: no FMA contraction in the bit-exact units
 
 sys.path.insert(0, HERE)
@@ -58,7 +64,8 @@ def build(verbose=False):
         objs = list(ex.map(one, srcs))
     rt = os.path.join(OUT_DIR, "emu_rt.o")
     subprocess.check_call([CXX] + FLAGS + ["-c", os.path.join(HERE, "emu_rt.cpp"), "-o", rt])
-    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + [rt])
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) +
+                          ["-o", LIB] + objs + [rt])
     with open(stamp, "w") as f:
         f.write(dig)
     if verbose:

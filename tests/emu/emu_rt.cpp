@@ -116,12 +116,27 @@ static void run_block(Dim3 bid, Dim3 grid, Dim3 block, const void* kernarg) {
         W.parity = 0;
         for (int i = 0; i < W.n; ++i) W.lanes[i] = &P.lanes[64 * w + i];
     }
+    // Y5M_EMU_WAVE_ORDER: the order in which the scheduler visits the waves of a workgroup -- 0 ascending (default), 1
+    // descending, >= 2 a different pseudo-random permutation per scheduler pass (seeded by the value and the block). No order
+    // between waves is guaranteed on the GPU except at barriers, so every order must give the same results: a test that passes
+    // ascending and fails otherwise has found a missing barrier (read-after-write or write-after-read through LDS).
+    static const int wave_order = [] { const char* e = getenv("Y5M_EMU_WAVE_ORDER"); return e ? atoi(e) : 0; }();
+    unsigned rng = (unsigned)wave_order * 2654435761u + bid.x * 40503u + bid.y * 977u + 12345u;
+    int order[MAX_THREADS_PER_BLOCK / 64];
     int live = nthreads;
     while (live > 0) {
         bool progress = false;
         int at_barrier = 0;
         live = 0;
-        for (int w = 0; w < nwaves; ++w) {
+        for (int w = 0; w < nwaves; ++w) order[w] = wave_order == 1 ? nwaves - 1 - w : w;
+        if (wave_order >= 2)
+            for (int w = nwaves - 1; w > 0; --w) {
+                rng = rng * 1664525u + 1013904223u;
+                const int j = (int)((rng >> 8) % (unsigned)(w + 1));
+                const int t = order[w]; order[w] = order[j]; order[j] = t;
+            }
+        for (int wi = 0; wi < nwaves; ++wi) {
+            const int w = order[wi];
             Wave& W = P.waves[w];
             for (int i = 0; i < W.n; ++i) {
                 Lane* l = W.lanes[i];
@@ -201,9 +216,12 @@ static bool stopping = false;
 static void work_on(Job* j) {
     pool.init();
     pool.body = j->body;
+    // Y5M_EMU_BLOCK_ORDER=1: workgroups are taken from the END of the grid (no kernel may depend on the dispatch order)
+    static const int block_order = [] { const char* e = getenv("Y5M_EMU_BLOCK_ORDER"); return e ? atoi(e) : 0; }();
     for (;;) {
-        const long b = j->next.fetch_add(1);
+        long b = j->next.fetch_add(1);
         if (b >= j->total) break;
+        if (block_order == 1) b = j->total - 1 - b;
         const Dim3 bid((unsigned)(b % j->grid.x), (unsigned)((b / j->grid.x) % j->grid.y), (unsigned)(b / ((long)j->grid.x * j->grid.y)));
         run_block(bid, j->grid, j->block, j->kernarg);
     }
