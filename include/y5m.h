@@ -65,6 +65,13 @@ int y5m_decode_scale(const float* logits, int B, int naxs, int ny, int nx, int n
 int y5m_decode_targets_scale(const float* tgt, int B, int naxs, int ny, int nx, float stride,
                              float* out, int64_t N_total, int64_t row_offset, void* stream);
 
+/* Replaces the per-scale counting of YOLO_EVAL.check_class_accuracy (utils/validation_utils.py:58-68): over the cells the dense
+ * target tgt (cells x 6) marks as objects (tgt[..., 4] == 1), counts[0] += their number, counts[1] += those with
+ * argmax(out[..., 5:]) == tgt[..., 5], counts[2] += those with sigmoid(out[..., 0]) > conf_threshold (channel 0, as the
+ * reference reads it, :66). out: cells x nch logits. counts: three int64 on the device, zeroed by the caller. */
+int y5m_class_obj_accuracy(const float* out, const float* tgt, int64_t cells, int nch, float conf_threshold,
+                           int64_t* counts, void* stream);
+
 /* Replaces utils/bboxes_utils.py:175-209 non_max_suppression (per-image loop :185-203 incl. the
  * torchvision.ops.nms call :195) for a whole batch in ONE launch (one workgroup per image).
  * boxes (B,N,6) rows [class, score, x, y, w, h] f32 (not modified).

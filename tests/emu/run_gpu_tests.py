@@ -68,6 +68,10 @@ def main():
             for kw in expand(fn):
                 if "golden" in params:
                     kw = dict(kw, golden=golden)
+                mp = None
+                if "monkeypatch" in params:
+                    import pytest
+                    mp = kw["monkeypatch"] = pytest.MonkeyPatch()
                 for pn in params:                      # module-level fixtures without arguments
                     fx = getattr(mod, pn, None)
                     if pn not in kw and fx is not None and hasattr(fx, "_get_wrapped_function"):
@@ -80,7 +84,10 @@ def main():
                     st = "FAIL " + type(e).__name__ + ": " + str(e).replace("\n", " ")[:300]
                     if os.environ.get("EMU_TB"):
                         traceback.print_exc()
-                show = {k: v for k, v in kw.items() if k != "golden" and not hasattr(getattr(mod, k, None), "_get_wrapped_function")}
+                finally:
+                    if mp is not None:
+                        mp.undo()
+                show = {k: v for k, v in kw.items() if k not in ("golden", "monkeypatch") and not hasattr(getattr(mod, k, None), "_get_wrapped_function")}
                 print(f"{time.time() - t:7.2f}s {name} {show} {st}", flush=True)
 
 

@@ -459,3 +459,34 @@ def test_sparse_head_gradient_path_equals_dense(anchors, dtype):
         assert float((d0 == d1).float().mean()) > 0.999, i
         np.testing.assert_allclose(d1.cpu().numpy(), d0.cpu().numpy(), rtol=1e-2 if dtype == "bf16" else 1e-5, atol=1e-9)
         np.testing.assert_allclose(res["sparse"][2][i].cpu().numpy(), res["dense"][2][i].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 3, 20, 20), (3, 3, 1, 1)])
+def test_class_obj_accuracy_counts_bit_exact(shape):
+    """y5m_class_obj_accuracy against the reference's masked counting (utils/validation_utils.py:58-68) on random logits with
+    TIED class maxima (torch.argmax takes the first), cell counts that are not multiples of a wave, no object at all in one
+    case, and the objectness read from channel 0 as the reference does (:66)."""
+    from yolov5m_amd import _lib
+    B, A, ny, nx = shape
+    g = torch.Generator().manual_seed(B * 100 + ny)
+    out = torch.randn((B, A, ny, nx, 85), generator=g)
+    out[..., 5:] = torch.round(out[..., 5:] * 2) / 2                      # many equal class logits: ties
+    y = torch.zeros((B, A, ny, nx, 6))
+    obj = torch.rand((B, A, ny, nx), generator=g) < (0.0 if shape[2] == 1 else 0.3)
+    y[..., 4] = obj.float()
+    y[..., 5] = torch.randint(0, 80, (B, A, ny, nx), generator=g).float()
+    # half of the object cells get the label their argmax will produce
+    am = torch.argmax(out[..., 5:], dim=-1).float()
+    take = torch.rand((B, A, ny, nx), generator=g) < 0.5
+    y[..., 5] = torch.where(take, am, y[..., 5])
+    conf = 0.6
+    m = y[..., 4] == 1
+    want = [int(m.sum()), int((torch.argmax(out[..., 5:][m], dim=-1) == y[..., 5][m]).sum()),
+            int(((torch.sigmoid(out[..., 0]) > conf)[m] == y[..., 4][m]).sum())]
+    od, yd = out.to(DEV).contiguous(), y.to(DEV).contiguous()
+    counts = torch.zeros(3, dtype=torch.int64, device=DEV)
+    for _ in range(2):                                                    # accumulates: the second call doubles every counter
+        _lib.check(_lib.lib().y5m_class_obj_accuracy(_lib.ptr(od), _lib.ptr(yd), B * A * ny * nx, 85, conf, _lib.ptr(counts),
+                                                     _lib.stream_ptr()), "y5m_class_obj_accuracy")
+    torch.cuda.synchronize()
+    assert counts.cpu().tolist() == [2 * v for v in want], (counts.cpu().tolist(), want)

@@ -102,6 +102,7 @@ _SIGS = {
     "y5m_persistent_cu_count": (c_int, []),
     "y5m_decode_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p,
                                  c_int64, c_int64, c_void_p]),
+    "y5m_class_obj_accuracy": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "y5m_decode_targets_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64,
                                          c_int64, c_void_p]),
     "y5m_nms_workspace_bytes": (c_size_t, [c_int, c_int64]),

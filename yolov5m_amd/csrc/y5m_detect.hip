@@ -267,6 +267,67 @@ extern "C" int y5m_decode_targets_scale(const float* tgt, int B, int naxs, int n
 }
 
 // =================================================================================================
+// check_class_accuracy (reference utils/validation_utils.py:44-83): per scale, over the cells the dense target marks as
+// objects (t[..., 4] == 1): how many there are, how many have argmax(logits[5:]) == t[..., 5], how many have
+// sigmoid(logits[..., 0]) > conf (the reference reads the objectness from channel 0, :66 -- reproduced). One wave scans 64
+// cells' flags at a time and resolves the marked ones cooperatively (the 5 + nc logits of a row across the lanes, first
+// maximum wins like torch.argmax); three 64-bit counters per launch, accumulated with atomics (the caller zeroes them).
+// =================================================================================================
+__global__ __launch_bounds__(256) void class_obj_accuracy_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                                 int64_t cells, int nch, float conf, unsigned long long* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    unsigned long long n_obj = 0, n_cls = 0, n_ok = 0;
+    for (int64_t c0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; c0 < cells; c0 += nwaves * 64) {
+        const int64_t cell = c0 + lane;
+        const bool isobj = cell < cells && tgt[cell * 6 + 4] == 1.0f;                       // :60
+        unsigned long long m = __ballot(isobj);
+        while (m) {
+            const int cl = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const float* row = out + (c0 + cl) * nch;
+            // argmax over channels 5 .. nch-1: every lane takes channels lane+5, lane+69, ...; (value, index) reduced with
+            // "greater value, or equal value and smaller index" = the first maximum
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int ch = 5 + lane; ch < nch; ch += 64) {
+                const float v = row[ch];
+                if (v > bv || (v == bv && ch < bi) || bi == 0x7fffffff) { bv = v; bi = ch; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) {
+                const float t5 = tgt[(c0 + cl) * 6 + 5];
+                const float s0 = 1.0f / (1.0f + expf(-row[0]));                              // :66 (channel 0)
+                n_obj += 1;
+                n_cls += ((float)(bi - 5) == t5) ? 1 : 0;                                     // :62
+                n_ok += (s0 > conf) ? 1 : 0;                                                  // :67 (obj_preds == 1 on object cells)
+            }
+        }
+    }
+    if (lane == 0 && n_obj) {
+        atomicAdd(&counts[0], n_obj);
+        atomicAdd(&counts[1], n_cls);
+        atomicAdd(&counts[2], n_ok);
+    }
+}
+
+extern "C" int y5m_class_obj_accuracy(const float* out, const float* tgt, int64_t cells, int nch, float conf_threshold,
+                                      int64_t* counts, void* stream) {
+    Y5M_REQUIRE(out && tgt && counts && nch > 5 && cells >= 0, "y5m_class_obj_accuracy: bad arguments");
+    if (cells == 0) return Y5M_OK;
+    const int64_t blocks = (cells + 255) / 256;
+    hipLaunchKernelGGL(class_obj_accuracy_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, y5m_stream(stream),
+                       out, tgt, cells, nch, conf_threshold, reinterpret_cast<unsigned long long*>(counts));
+    Y5M_CHECK_LAUNCH("class_obj_accuracy_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
 // NMS  (reference utils/bboxes_utils.py:175-209 + torchvision 0.12 nms_kernel.cpp semantics)
 // =================================================================================================
 #define NMS_T 1024          // threads per image-workgroup (16 waves)

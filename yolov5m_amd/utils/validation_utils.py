@@ -1,8 +1,8 @@
 """Eval path of the reference (utils/validation_utils.py:11-144), same class and method names.
 
 The heavy parts are the native hot path: eval-mode model forward (folded-BN conv epilogues), decode of predictions
-AND of dense targets (`cells_to_bboxes`, is_pred True / False), per-image NMS at CONF_THRESHOLD. What stays in torch
-is the bookkeeping around them (boolean-mask counting, dict packing). mAP itself is torchmetrics'
+AND of dense targets (`cells_to_bboxes`, is_pred True / False), per-image NMS at CONF_THRESHOLD, and the masked counting of check_class_accuracy
+(y5m_class_obj_accuracy). What stays in torch is the dict packing. mAP itself is torchmetrics'
 MeanAveragePrecision -- not part of the hot path: used when importable, otherwise `map_pr_rec` returns the
 (preds, targets) lists it would have been fed."""
 import csv
@@ -33,25 +33,33 @@ class YOLO_EVAL:
         self.obj_accuracy = None
 
     def check_class_accuracy(self, model, loader):
-        """reference :44-83. Returns (class_accuracy, obj_accuracy) as 0-dim tensors. NOTE the reference reads the
-        objectness from channel 0 (`out[i][..., 0]`, :66), not channel 4: parity is defined on that."""
+        """reference :44-83. Returns (class_accuracy, obj_accuracy) as 0-dim tensors. The per-scale masked counting (:58-68) is
+        one native launch per scale (y5m_class_obj_accuracy) into three device counters -- no boolean-mask gathers, no host
+        sync inside the loop. NOTE the reference reads the objectness from channel 0 (`out[i][..., 0]`, :66), not channel 4:
+        parity is defined on that."""
+        from .. import _lib
+        L = _lib.lib()
         model.eval()
-        tot_class_preds, correct_class = 0, 0
-        tot_obj, correct_obj = 0, 0
+        counts = None
         for images, y in loader:
             images = images.to(self.device).float() / 255                                     # :52-53
             with torch.no_grad():
                 out = model(images)
+            if counts is None:
+                counts = torch.zeros(3, dtype=torch.int64, device=out[0].device)             # objects, class hits, objectness hits
             for i in range(3):
-                yi = y[i].to(self.device)
-                obj = yi[..., 4] == 1                                                         # :60
-                correct_class += torch.sum(torch.argmax(out[i][..., 5:][obj], dim=-1) == yi[..., 5][obj])
-                tot_class_preds += torch.sum(obj)
-                obj_preds = torch.sigmoid(out[i][..., 0]) > self.conf_threshold               # :66
-                correct_obj += torch.sum(obj_preds[obj] == yi[..., 4][obj])
-                tot_obj += torch.sum(obj)
-        class_accuracy = correct_class / (tot_class_preds + 1e-16)
-        obj_accuracy = correct_obj / (tot_obj + 1e-16)
+                o = out[i] if (out[i].dtype == torch.float32 and out[i].is_contiguous()) else out[i].float().contiguous()
+                yi = y[i].to(o.device, non_blocking=True).float().contiguous()
+                _lib.require_cuda(o, yi)
+                if o.shape[:-1] != yi.shape[:-1] or yi.shape[-1] != 6:
+                    raise _lib.Y5MError(f"check_class_accuracy: scale {i}: logits {tuple(o.shape)} vs targets {tuple(yi.shape)}")
+                _lib.check(L.y5m_class_obj_accuracy(_lib.ptr(o), _lib.ptr(yi), o.numel() // o.shape[-1], o.shape[-1],
+                                                    float(self.conf_threshold), _lib.ptr(counts), _lib.stream_ptr()),
+                           "y5m_class_obj_accuracy")
+        if counts is None:
+            counts = torch.zeros(3, dtype=torch.int64, device=self.device)
+        class_accuracy = counts[1] / (counts[0] + 1e-16)                                      # :72-73
+        obj_accuracy = counts[2] / (counts[0] + 1e-16)
         if self.save_logs:
             self.class_accuracy = round(float(class_accuracy), 3)
             self.obj_accuracy = round(float(obj_accuracy), 3)
