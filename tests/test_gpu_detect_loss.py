@@ -490,3 +490,33 @@ def test_class_obj_accuracy_counts_bit_exact(shape):
                                                      _lib.stream_ptr()), "y5m_class_obj_accuracy")
     torch.cuda.synchronize()
     assert counts.cpu().tolist() == [2 * v for v in want], (counts.cpu().tolist(), want)
+
+
+def test_dense_targets_builder_matches_dataset_algorithm(anchors):
+    """utils/validation_utils.DenseTargets (the datasets' dense target builder, dataset.py:337-414 -- the same
+    algorithm and the same in-place anchor decay as YOLO_LOSS.build_targets) for two consecutive batches against the oracle's
+    restatement run image by image (oracle pinned to the real reference's loss.build_targets by g12): bit-exact, anchor
+    state included; an image without boxes; non-square images."""
+    from yolov5m_amd import config
+    from yolov5m_amd.utils.validation_utils import DenseTargets
+    dt = DenseTargets(config.ANCHORS, device=DEV)
+    ref = loss_ref.YoloLossRef(anchors)
+    assert torch.equal(dt.anchors, ref.anchors)
+    rng = np.random.RandomState(5)
+    for hw in ((96, 128), (64, 64)):
+        labels = []
+        for b in range(3):
+            n = [4, 0, 7][b]
+            lab = np.zeros((n, 5), np.float64)
+            lab[:, 0] = rng.randint(0, 80, n)
+            lab[:, 1:3] = rng.uniform(0.05, 0.95, (n, 2))
+            lab[:, 3:5] = rng.uniform(0.02, 0.6, (n, 2))
+            labels.append(lab)
+        got = dt(labels, hw)
+        shapes = [(hw[0] // s, hw[1] // s) for s in (8, 16, 32)]
+        want = [ref.build_targets(shapes, lab) for lab in labels]
+        for i in range(3):
+            w = torch.stack([t[i] for t in want], 0)
+            assert tuple(got[i].shape) == tuple(w.shape)
+            assert torch.equal(got[i].cpu(), w), (hw, i, float((got[i].cpu() - w).abs().max()))
+        assert torch.equal(dt.anchors, ref.anchors)

@@ -14,6 +14,62 @@ from .bboxes_utils import non_max_suppression
 from .plot_utils import cells_to_bboxes
 
 
+class DenseTargets:
+    """The dense target builder of the reference's datasets (Validation_Dataset.__getitem__, dataset.py:337-414; the training
+    dataset's :124-196 is the same code): per image, every box claims the cell of its best free anchor on each scale
+    ([x_cell, y_cell, w_cell, h_cell, 1, class]) and marks further well-matching anchors as ignored (-1) -- for a WHOLE BATCH
+    in one native launch (y5m_yolo_build_targets, the kernel behind YOLO_LOSS.build_targets: the algorithm is the same,
+    loss.py:101-192). State like the dataset object's: `anchors` (3,3,2) in stride units (dataset.py:240), which the
+    reference's iou_width_height divides by 640 IN PLACE once per box (utils/bboxes_utils.py:18) -- reproduced, bit for bit,
+    because which anchors match depends on it. Returns [(B,3,ny,nx,6)] * 3 on the device: what YOLO_EVAL.check_class_accuracy
+    and cells_to_bboxes(is_pred=False) consume."""
+
+    def __init__(self, anchors, S=(8, 16, 32), ignore_iou_thresh=0.5, device=None, strided=False):
+        """anchors: config.ANCHORS (pixels, what the dataset constructor receives, :216) -- or, with strided=True, a tensor
+        already in stride units such as model.head.anchors"""
+        import numpy as np
+        from .. import _lib
+        self._np, self._lib = np, _lib
+        self.S = [int(v) for v in S]
+        dev = device or _lib.DEVICE
+        a = torch.as_tensor(anchors, dtype=torch.float32)
+        if strided:
+            a = a.reshape(3, 3, 2).clone()
+        else:                                           # :240
+            a = a.view(3, -1, 2) / torch.tensor(self.S).repeat(6, 1).T.reshape(3, 3, 2)
+        self._anc = [a.to(dev).contiguous(), torch.zeros((3, 3, 2), dtype=torch.float32, device=dev)]
+        _lib.require_cuda(self._anc[0])
+        self.ignore_iou_thresh = float(ignore_iou_thresh)
+
+    @property
+    def anchors(self):
+        """the dataset object's `self.anchors` after every in-place decay so far (CPU copy)"""
+        return self._anc[0].detach().to("cpu")
+
+    def __call__(self, labels, img_hw):
+        """labels: per image an (n_i, 5) array [cls, x, y, w, h] (normalised, dataset.py:320-323); img_hw: (H, W) of the batch"""
+        np, _lib = self._np, self._lib
+        L = _lib.lib()
+        dev = self._anc[0].device
+        B = len(labels)
+        off = np.zeros(B + 1, np.int32)
+        off[1:] = np.cumsum([len(b) for b in labels])
+        flat = (np.concatenate([np.asarray(b, np.float64).reshape(-1, 5) for b in labels], 0) if off[-1] else
+                np.zeros((1, 5), np.float64))
+        d_boxes = torch.from_numpy(np.ascontiguousarray(flat)).to(dev, non_blocking=True)
+        d_off = torch.from_numpy(off).to(dev, non_blocking=True)
+        shapes = [(int(img_hw[0] / s), int(img_hw[1] / s)) for s in self.S]                      # :337-339
+        dense = [torch.empty((B, 3, ny, nx, 6), dtype=torch.float32, device=dev) for ny, nx in shapes]
+        _lib.check(L.y5m_yolo_build_targets(_lib.ptr(d_boxes), _lib.ptr(d_off), B, _lib.int_array([s[0] for s in shapes]),
+                                            _lib.int_array([s[1] for s in shapes]), _lib.int_array(self.S),
+                                            _lib.ptr(self._anc[0]), _lib.ptr(self._anc[1]), self.ignore_iou_thresh,
+                                            _lib.ptr_array(dense), _lib.stream_ptr()), "y5m_yolo_build_targets")
+        if off[-1]:
+            self._anc.reverse()
+        self._keep = (d_boxes, d_off)                   # until the launch has run
+        return dense
+
+
 class YOLO_EVAL:
     def __init__(self, save_logs, conf_threshold, nms_iou_thresh, map_iou_thresh, device, filename, resume):
         """reference :12-42"""
