@@ -13,11 +13,17 @@ CSRC = os.path.join(ROOT, "yolov5m_amd", "csrc")
 # the fibers switch stacks behind the sanitizer's back). Load it in a python started with LD_PRELOAD=<asan runtime>
 # (tests/emu/asan_run.sh): an out-of-bounds read or write of a kernel on a tensor -- silent on the GPU -- aborts with a report.
 ASAN = os.environ.get("Y5M_EMU_ASAN") == "1"
-OUT_DIR = os.path.join(ROOT, "build", "emu_asan" if ASAN else "emu")
+FAST_EXP = os.environ.get("Y5M_EMU_FAST_EXP") == "1"       # __expf as the GPU computes it (see include/hip/hip_runtime.h)
+RCP_ULP = os.environ.get("Y5M_EMU_RCP_ULP", "")          # systematic n-ulp bias of v_rcp_f32 (sensitivity experiments)
+OUT_DIR = os.path.join(ROOT, "build", "emu_asan" if ASAN else ("emu_fastexp" if FAST_EXP else "emu") + (f"_rcp{RCP_ULP}" if RCP_ULP else ""))
 LIB = os.path.join(OUT_DIR, "liby5m_emu.so")
 CXX = os.environ.get("Y5M_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-w", "-pthread",
          "-I", os.path.join(HERE, "include"), "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+if FAST_EXP:
+    FLAGS += ["-DY5M_EMU_FAST_EXP"]
+if RCP_ULP:
+    FLAGS += [f"-DY5M_EMU_RCP_ULP={int(RCP_ULP)}"]
 if ASAN:
     FLAGS += ["-fsanitize=address", "-shared-libasan", "-mllvm", "-asan-stack=0", "-fno-omit-frame-pointer", "-g1"]
 EXACT = {"y5m_detect.hip", "y5m_loss.hip"}          # same rule as csrc/Makefile: no FMA contraction in the bit-exact units

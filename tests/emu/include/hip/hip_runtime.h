@@ -104,7 +104,13 @@ static inline unsigned __float_as_uint(float f) { return __builtin_bit_cast(unsi
 static inline int __float_as_int(float f) { return __builtin_bit_cast(int, f); }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int __mul24(int a, int b) { return ((a << 8) >> 8) * ((b << 8) >> 8); }
+// __expf on the GPU is v_exp_f32(x * log2(e)) with the product rounded to f32 (argument error ~ |x| 6e-8 relative in the result);
+// -DY5M_EMU_FAST_EXP models exactly that, the default is libm's expf (tools: attribution of the bf16 first-step loss shift)
+#ifdef Y5M_EMU_FAST_EXP
+#define __expf(x) exp2f((float)(x) * 1.44269504088896341f)
+#else
 #define __expf(x) expf(x)
+#endif
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
@@ -243,7 +249,17 @@ static inline int __builtin_amdgcn_sbfe(int v, int off, int width) {
     if (width == 0) return 0;
     return (int)((unsigned)v << (32 - off - width)) >> (32 - width);
 }
-static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+// v_rcp_f32 is accurate to 1 ulp, its rounding is not specified: the default is the correctly rounded quotient;
+// -DY5M_EMU_RCP_ULP=n moves every result by n ulps (a worst-case systematic bias, for sensitivity experiments)
+#ifndef Y5M_EMU_RCP_ULP
+#define Y5M_EMU_RCP_ULP 0
+#endif
+static inline float __builtin_amdgcn_rcpf(float x) {
+    float r = 1.0f / x;
+    if (Y5M_EMU_RCP_ULP != 0 && r == r && r != 0.0f && fabsf(r) < 3.0e38f)
+        r = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + (r > 0 ? Y5M_EMU_RCP_ULP : -(Y5M_EMU_RCP_ULP)));
+    return r;
+}
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline const void* __builtin_amdgcn_kernarg_segment_ptr() { return emu::g.kernarg; }
