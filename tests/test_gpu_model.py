@@ -616,10 +616,15 @@ def test_bf16_train_step_vs_quantisation_aware_oracle(golden):
         assert d_hip <= 1.25 * d_q + 0.01, (i, d_hip, d_q)
     gh = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
     print(f"gradient L2 norm: hip_bf16 {gh:.3f}  quant_oracle {res[True][2]:.3f}  f32_oracle {res[False][2]:.3f}")
-    # 8 %: the norm is as chaotic as the logits (two bf16 evaluations of this network differ by 23-48 % element-wise): the
-    # three-launch BatchNorm form gives 187.9 here, the accumulator-row form (f64 sums of the same f32 tile sums) 199-202
-    # from run to run (the order of its atomic adds is free), against 192.07 for the quantised oracle and 189.46 for f32
-    assert abs(gh - res[True][2]) <= 0.08 * res[True][2], (gh, res[True][2], res[False][2])
+    # The norm is as chaotic as the logits (two bf16 evaluations of this network differ by 23-48 % element-wise): the three-launch
+    # BatchNorm form gives 187.9, the accumulator-row form 199-202 from run to run on the GPU (the order of its atomic adds is free),
+    # the CPU executor of tests/emu 194.5 -- and the quantised ORACLE itself gives 192.07 on the GPU boxes' host CPUs and 175.47 on the
+    # build container's (another BLAS summation order, other bf16 roundings), a 9 % spread of the yardstick. Until round 4 this
+    # asserted 8 % against the quantised oracle, i.e. inside that spread. The machine-independent yardstick is the f32 oracle
+    # (189.46): 12 % of it, and a loose 15 % against the quantised one; the element-wise statement about bf16 gradients is
+    # test_bf16_per_layer_backward_on_engine_operands (2e-2 per tensor, layer-local, not chaotic).
+    assert abs(gh - res[False][2]) <= 0.12 * res[False][2], (gh, res[True][2], res[False][2])
+    assert abs(gh - res[True][2]) <= 0.15 * res[True][2], (gh, res[True][2], res[False][2])
 
 
 @pytest.mark.parametrize("dtype,rtol", [("f32", 1e-4), ("bf16", 3e-3)])
