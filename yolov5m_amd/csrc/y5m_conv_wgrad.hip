@@ -469,27 +469,85 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
     const unsigned ldyb = (unsigned)(P.lddy * 2), ldxb = (unsigned)(P.ldx * 2);
     const int dh = P.dh0 + ty * P.dhs;
     u32x4 ry[C::NLDY], rx[C::NLDX];
-    auto load_chunk = [&](int chk) __attribute__((always_inline)) {
+    // Addresses (round 4: tools/isa_audit.py counted 213-321 VALU + 111-136 SALU per chunk against 27 MFMAs -- two divisions, the
+    // bounds tests and the multiplies PER 16-BYTE PIECE AND LANE). A chunk is WK consecutive runs, and everything that depends on
+    // the run -- (image, output row, run of the row), the input row of this block's kernel row, their validity -- is the same
+    // for all lanes: it lives in scalar registers, advances by WK runs per chunk with adds and a carry, and a piece only SELECTS
+    // its run's base offset / limit (yks / xks are loop invariant) and adds its own loop-invariant lane constant.
+    unsigned ycst[C::NLDY], xcst[C::NLDX];
+#pragma unroll
+    for (int i = 0; i < C::NLDY; ++i) ycst[i] = (unsigned)ypx[i] * ldyb + (unsigned)(ycc[i] * 16);
+#pragma unroll
+    for (int i = 0; i < C::NLDX; ++i) xcst[i] = (unsigned)xpx[i] * ldxb + (unsigned)(xcc[i] * 16);
+    // run 0 of the NEXT chunk to load: its index su0 and, advanced run by run with adds (a run that starts a new output row
+    // recomputes them: one uniform branch, taken once per row): the run's number in its row (sj), its output row and image (soy,
+    // sb), the byte offset of its first dY pixel (sybase), of the X pixel its tap 0 reads (sxbase; garbage while the input row is
+    // outside the image: sxix then makes every pixel fail its bounds test), that pixel's column (sxix, or a huge value) and the
+    // pixels left in the output row (sylim)
+    int su0, sj, soy, sb, sylim, sxix;
+    unsigned sybase, sxbase;
+    auto row_start = [&]() __attribute__((always_inline)) {           // the scalars of run 0 of output row (sb, soy)
+        const int iy = soy * P.sy + dh;
+        sybase = (unsigned)((sb * P.Hg + soy) * P.Wg) * ldyb;
+        sxbase = ((unsigned)((sb * P.Hin + iy) * P.Win) + (unsigned)P.dw0) * ldxb;
+        sxix = (unsigned)iy < (unsigned)P.Hin ? P.dw0 : 0x40000000;
+        sylim = P.Wg;
+        sj = 0;
+    };
+    const unsigned ystep = 32u * ldyb, xstep = (unsigned)(32 * P.sx) * ldxb;
+    {
+        su0 = __builtin_amdgcn_readfirstlane(ch_lo * WK);
+        int row, j, b, oy;
+        fast_divmod(su0, spr, rcpS, row, j);
+        fast_divmod(row, P.Hg, rcpH, b, oy);
+        j = __builtin_amdgcn_readfirstlane(j);
+        soy = __builtin_amdgcn_readfirstlane(oy); sb = __builtin_amdgcn_readfirstlane(b);
+        row_start();
+        sj = j; sybase += (unsigned)j * ystep; sxbase += (unsigned)j * xstep; sylim -= 32 * j;
+        if (sxix != 0x40000000) sxix += 32 * P.sx * j;
+    }
+    auto load_next = [&]() __attribute__((always_inline)) {
+        unsigned ybase[WK], xbase[WK];
+        int ylim[WK], xix0[WK];
+#pragma unroll
+        for (int k = 0; k < WK; ++k) {
+            const bool valid = su0 + k < nruns;
+            ybase[k] = sybase;
+            ylim[k] = valid ? sylim : 0;                                  // a piece is inside the row while its pixel < ylim
+            xix0[k] = valid ? sxix : 0x40000000;                           // (no input row / no such run: every pixel out of range)
+            xbase[k] = sxbase;
+            // the next run (uniform: scalar adds and one scalar branch)
+            if (++sj == spr) {
+                if (++soy == P.Hg) { soy = 0; ++sb; }
+                row_start();
+            } else {
+                sybase += ystep; sxbase += xstep; sylim -= 32;
+                sxix = sxix != 0x40000000 ? sxix + 32 * P.sx : sxix;
+            }
+        }
+        su0 += WK;
+        // piece i of a thread is piece tid + 256 i of the chunk: its run is one of the (at most two) runs that 256-piece window
+        // touches -- known at compile time, so a piece selects between two scalars, whatever WK is
+        constexpr int PERY = 32 * (C::N / 8), PERX = C::NPX * 6;
 #pragma unroll
         for (int i = 0; i < C::NLDY; ++i) {
-            const int u = chk * WK + yks[i];
-            int row, j;
-            fast_divmod(u, spr, rcpS, row, j);                        // row = b * Hg + oy
-            const int ox = 32 * j + ypx[i];
-            const bool ok = yks[i] >= 0 && u < nruns && ox < P.Wg;
-            const unsigned m = (unsigned)(row * P.Wg + ox);
-            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, ok ? m * ldyb + (unsigned)(ycc[i] * 16) : OOB, 0, 0);
+            const int ka = (256 * i) / PERY < WK ? (256 * i) / PERY : WK - 1, kb = (256 * i + 255) / PERY < WK ? (256 * i + 255) / PERY : WK - 1;
+            unsigned base = ybase[ka];
+            int lim = ylim[ka];
+#pragma unroll
+            for (int k = ka + 1; k <= kb; ++k) { base = yks[i] == k ? ybase[k] : base; lim = yks[i] == k ? ylim[k] : lim; }
+            const bool ok = yks[i] >= 0 && ypx[i] < lim;
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, ok ? base + ycst[i] : OOB, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < C::NLDX; ++i) {
-            const int u = chk * WK + xks[i];
-            int row, j, b, oy;
-            fast_divmod(u, spr, rcpS, row, j);
-            fast_divmod(row, P.Hg, rcpH, b, oy);
-            const int iy = oy * P.sy + dh, ix = 32 * j * P.sx + P.dw0 + xpx[i];
-            const bool ok = xks[i] >= 0 && u < nruns && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            const unsigned pix = __umul24((unsigned)(b * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
-            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? __umul24(pix, ldxb) + (unsigned)(xcc[i] * 16) : OOB, 0, 0);
+            const int ka = (256 * i) / PERX < WK ? (256 * i) / PERX : WK - 1, kb = (256 * i + 255) / PERX < WK ? (256 * i + 255) / PERX : WK - 1;
+            unsigned base = xbase[ka];
+            int ix0 = xix0[ka];
+#pragma unroll
+            for (int k = ka + 1; k <= kb; ++k) { base = xks[i] == k ? xbase[k] : base; ix0 = xks[i] == k ? xix0[k] : ix0; }
+            const bool ok = xks[i] >= 0 && (unsigned)(ix0 + xpx[i]) < (unsigned)P.Win;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? base + xcst[i] : OOB, 0, 0);
         }
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
@@ -541,12 +599,12 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
     };
 
     if (ch_lo < ch_hi) {
-        load_chunk(ch_lo);
+        load_next();
         store_chunk();
         __syncthreads();
         for (int chk = ch_lo; chk < ch_hi; ++chk) {
             const bool more = chk + 1 < ch_hi;
-            if (more) load_chunk(chk + 1);
+            if (more) load_next();
             compute();
             __syncthreads();
             if (more) store_chunk();
