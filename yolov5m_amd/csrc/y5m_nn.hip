@@ -32,6 +32,26 @@ template <> __device__ __forceinline__ void load8_nt<float>(const float* p, floa
 #define LOAD8_STREAM load8_nt
 #endif
 
+// 8 elements as they lie in memory, unpacked later: a load whose VALUE is first touched in another basic block does not force a
+// `s_waitcnt vmcnt(0)` right behind it (tools/isa_audit.py "dep": bn_act_kernel's residual loads sat inside `if (res)` blocks
+// together with their bf16 -> f32 unpacking, so every row waited for ALL loads in flight before the next row was requested)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { nn_u32x4 q; };
+template <> struct Raw8<float> { nn_f32x4 a, b; };
+__device__ __forceinline__ void raw_load8(const bf16_t* p, Raw8<bf16_t>& r) { r.q = *reinterpret_cast<const nn_u32x4*>(p); }
+__device__ __forceinline__ void raw_load8(const float* p, Raw8<float>& r) {
+    r.a = *reinterpret_cast<const nn_f32x4*>(p);
+    r.b = *(reinterpret_cast<const nn_f32x4*>(p) + 1);
+}
+__device__ __forceinline__ void raw_unpack8(const Raw8<bf16_t>& r, float v[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r.q[i] << 16); v[2 * i + 1] = __uint_as_float(r.q[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void raw_unpack8(const Raw8<float>& r, float v[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+}
+
 #define DISPATCH_T(dtype, ...)                                         \
     if ((dtype) == Y5M_BF16) { using T = bf16_t; __VA_ARGS__ }        \
     else if ((dtype) == Y5M_F32) { using T = float; __VA_ARGS__ }     \
@@ -491,7 +511,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
     int64_t m = (int64_t)blockIdx.x * RP + rl;
     const bool active = rl < RP;
     float sc[8], sh[8];
-    float v[4][8], r[4][8];
+    float v[4][8];
+    Raw8<T> r[4];                                           // residual rows, unpacked where they are added (finish4)
     // FUSED: the first four rows are requested BEFORE the coefficient prologue, so that its round trip to the accumulator
     // rows and its f64 arithmetic run under their HBM latency (without this every workgroup starts with ~3 us of nothing in
     // flight: +4 us per launch with the ~4 rounds of workgroups a CU runs)
@@ -500,7 +521,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, v[u]);
-            if (res) load8<T>(res + (m + u * stride) * ldres + c, r[u]);
+            if (res) raw_load8(res + (m + u * stride) * ldres + c, r[u]);
         }
     }
     if constexpr (FUSED) {
@@ -543,11 +564,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
     auto finish4 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (res) raw_unpack8(r[u], rr);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 v[u][k] = v[u][k] * sc[k] + sh[k];
                 if (act == Y5M_ACT_SILU) v[u][k] = silu_f(v[u][k]);
-                if (res) v[u][k] += r[u][k];
+                if (res) v[u][k] += rr[k];
             }
             store8<T>(out + (m + u * stride) * ldout + c, v[u]);
         }
@@ -557,7 +580,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, v[u]);
-            if (res) load8<T>(res + (m + u * stride) * ldres + c, r[u]);
+            if (res) raw_load8(res + (m + u * stride) * ldres + c, r[u]);
         }
         finish4();
     }
