@@ -33,7 +33,8 @@ typedef y5m_bwd_stem_args BwdStemParams;
 #define BS_NF 27                           // accumulator fragments per wave: 9 taps x 3 dY fragments x 1 X fragment
 #define BS_TILE_F (BS_NF * 4 * 64)
 #define BS_RED (4 * BS_TILE_F * 4)         // first round of the wave reduction: 4 tiles
-#define BS_LDS ((BS_YB + BS_XB + BS_COEF) > BS_RED ? (BS_YB + BS_XB + BS_COEF) : BS_RED)
+#define BS_DUMMY 64                         // where the pieces behind the X tile (threads 1632..2047 of the fourth round) store
+#define BS_LDS ((BS_YB + BS_XB + BS_COEF + BS_DUMMY) > BS_RED ? (BS_YB + BS_XB + BS_COEF + BS_DUMMY) : BS_RED)
 #define BS_YP (BS_RUNS * 32 * 6)           // 16-byte pieces of dz (and of y) per chunk: 1536 = 3 per thread
 #define BS_XP (BS_RUNS * 3 * BS_NPX * 2)   // of x: 1632 -> 4 per thread, the last partly empty
 
@@ -95,30 +96,36 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
         const int rem2 = rem % (BS_NPX * 2);
         xpx[i] = rem2 >> 1;
         xhalf[i] = rem2 & 1;
-        xofs[i] = ((q < BS_XP ? xrun[i] : 0) * 3 + xty[i]) * BS_XG + xpx[i] * 32 + xhalf[i] * 16;
+        // (a piece behind the tile stores into the dummy region behind the coefficients: the store is unconditional)
+        xofs[i] = q < BS_XP ? (xrun[i] * 3 + xty[i]) * BS_XG + xpx[i] * 32 + xhalf[i] * 16 : BS_XB + BS_COEF + (lane & 3) * 16;
     }
     const float rcpS = 1.0f / (float)spr, rcpH = 1.0f / (float)P.H;
     const unsigned ldzb = (unsigned)(P.lddz * 2), ldyb = (unsigned)(P.ldy * 2), ldxb = (unsigned)(P.ldx * 2);
     u32x4 rz[3], ry[3], rx[4];
     unsigned okm = 0u;                                    // bit i: piece i of (dz, y) in flight is a real pixel
-    auto issue_zy = [&](int chunk, int i) __attribute__((always_inline)) {
+    // The streaming loop below is STRAIGHT-LINE code (round 4): "is there a next chunk", "is this piece a real pixel" and "is
+    // this piece inside the tile" are folded into load offsets (an out-of-range offset reads zeros and moves no data), a bit mask
+    // and a dummy store address. With branches around the loads the compiler could not count them across the blocks and waited
+    // with `s_waitcnt vmcnt(0)` at every use -- 21 full waits per chunk (tools/isa_audit.py), each of them also waiting for the
+    // pieces that had JUST been re-requested for the next chunk: a memory round trip per piece instead of one per chunk.
+    auto issue_zy = [&](int chunk, bool more, int i) __attribute__((always_inline)) {
         const int u = chunk * BS_RUNS + zrun[i];
         int row, j;
         fast_divmod(u, spr, rcpS, row, j);                // row = b * H + oy
         const int ox = 32 * j + zpx[i];
-        const bool ok = u < nruns && ox < P.W;
+        const bool ok = more && u < nruns && ox < P.W;
         const unsigned m = (unsigned)(row * P.W + ox);
         rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? m * ldzb + (unsigned)(zcc[i] * 16) : OOB, 0, 0);
         ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, ok ? m * ldyb + (unsigned)(zcc[i] * 16) : OOB, 0, 0);
         okm = (okm & ~(1u << i)) | ((ok ? 1u : 0u) << i);
     };
-    auto issue_x = [&](int chunk, int i) __attribute__((always_inline)) {
+    auto issue_x = [&](int chunk, bool more, int i) __attribute__((always_inline)) {
         const int u = chunk * BS_RUNS + xrun[i];
         int row, j, b, oy;
         fast_divmod(u, spr, rcpS, row, j);
         fast_divmod(row, P.H, rcpH, b, oy);
         const int iy = oy + xty[i] - 1, ix = 32 * j + xpx[i] - 1;
-        const bool ok = xrun[i] >= 0 && u < nruns && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
+        const bool ok = more && xrun[i] >= 0 && u < nruns && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
         const unsigned pix = __umul24((unsigned)(b * P.H + iy), (unsigned)P.W) + (unsigned)ix;
         rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? __umul24(pix, ldxb) + (unsigned)(xhalf[i] * 16) : OOB, 0, 0);
     };
@@ -138,15 +145,17 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
     };
 
     int chunk = blockIdx.x;
-    if (chunk < nchunks) {
+    {
+        const bool first = chunk < nchunks;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) issue_zy(chunk, i);
+        for (int i = 0; i < 3; ++i) issue_zy(chunk, first, i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_x(chunk, i);
+        for (int i = 0; i < 4; ++i) issue_x(chunk, first, i);
     }
     __syncthreads();                                      // coefficients are in place
     for (; chunk < nchunks; chunk += gridDim.x) {
         const int next = chunk + (int)gridDim.x;
+        const bool more = next < nchunks;
         // ---- phase A: dy from (dz, y) into the dY tile, x into the X tile; every piece is re-requested for the next chunk ------
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { sc[4 * h + k] = a0[k]; sh[4 * h + k] = a1[k]; kb[4 * h + k] = a2[k]; mu[4 * h + k] = a3[k]; kd[4 * h + k] = a4[k]; }
             }
-            const bool in = (okm >> i) & 1u;
+            const unsigned inm = 0u - ((okm >> i) & 1u);   // all ones for a real pixel
             float dy[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -176,14 +185,14 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
             }
             u32x4 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = in ? f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) : 0u;   // masked pixels contribute nothing
+            for (int q = 0; q < 4; ++q) o[q] = f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) & inm;     // masked pixels contribute nothing
             *reinterpret_cast<u32x4*>(ytile + zofs[i]) = o;
-            if (next < nchunks) issue_zy(next, i);
+            issue_zy(next, more, i);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (xrun[i] >= 0) *reinterpret_cast<u32x4*>(xtile + xofs[i]) = rx[i];
-            if (next < nchunks) issue_x(next, i);
+            *reinterpret_cast<u32x4*>(xtile + xofs[i]) = rx[i];
+            issue_x(next, more, i);
         }
         __syncthreads();
         // ---- phase C: this wave's run: 9 taps x 3 dY fragments, K = the run's 32 pixels ------------------------------------------
