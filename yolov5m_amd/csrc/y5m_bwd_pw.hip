@@ -195,7 +195,7 @@ __global__ __launch_bounds__(BP_THREADS, 2) void bwd_pw_kernel(const BwdPwParams
         // ---- phase A: dy from (dz, y), dy and x into the LDS tiles ---------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const bool in = (long long)tile * G::TP + pp[i] < P.M;
+            const unsigned inm = (long long)tile * G::TP + pp[i] < P.M ? 0xffffffffu : 0u;      // all ones for a row in front of M
             const int c0 = pc[i] * 8;
             float sc[8], sh[8], kb[8], mu[8], kd[8];
 #pragma unroll
@@ -221,12 +221,14 @@ __global__ __launch_bounds__(BP_THREADS, 2) void bwd_pw_kernel(const BwdPwParams
             }
             u32x4 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = in ? f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) : 0u;   // rows behind M contribute nothing
+            for (int q = 0; q < 4; ++q) o[q] = f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) & inm;   // rows behind M contribute nothing
             *reinterpret_cast<u32x4*>(ytile + lofs_y[i]) = o;
             *reinterpret_cast<u32x4*>(xtile + lofs_x[i]) = rx[i];
             // this piece's registers are free: the next tile's piece is requested right away and flies under the rest of
-            // phase A and phases C and B
-            if (tile + (int)gridDim.x < ntiles) issue_piece(tile + gridDim.x, i);
+            // phase A and phases C and B. UNCONDITIONALLY (behind the last tile the clamped row M - 1 is read once more and never
+            // used): with a branch around the request the compiler cannot count the loads across it and waits with vmcnt(0) for the
+            // last group of a tile -- i.e. also for the two groups it has just re-requested (round 4, tools/isa_audit.py)
+            issue_piece(tile + (int)gridDim.x, i);
         }
         __syncthreads();
 
