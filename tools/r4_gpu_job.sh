@@ -17,5 +17,5 @@ bash tools/profile_round.sh > $O/prof_round.log 2>&1
 bash tools/graph_hunt_r4.sh > $O/graph_hunt.log 2>&1; cat gpurun_out/graph_hunt_r4/summary.txt
 # 5. attribution of the bf16 first-step loss shift (IEEE division / accurate expf builds)
 bash tools/loss_shift_ab.sh > $O/loss_shift.log 2>&1; cat gpurun_out/loss_shift/summary.txt
-# 6. A/B of the round-4 scalar addressing of wgrad_rows_kernel against the round-3 form (alone on the chip and inside the step)
-bash tools/ab_wgrad_rows.sh > $O/ab_wgrad_rows.log 2>&1; cat gpurun_out/ab_wgrad_rows/alone.txt gpurun_out/ab_wgrad_rows/step.txt
+# 6. A/B of the four round-4 kernel changes (wgrad_rows, bn_act, bwd_stem, bwd_pw) against their round-3 forms (alone on the chip and inside the step)
+bash tools/ab_r4_kernels.sh > $O/ab_r4_kernels.log 2>&1; cat gpurun_out/ab_r4_kernels/alone.txt gpurun_out/ab_r4_kernels/step.txt
