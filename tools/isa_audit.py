@@ -3,8 +3,9 @@
 Per kernel instantiation: VGPRs / AGPRs / SGPRs, spilled registers, scratch bytes, static LDS bytes, waves per SIMD the
 register count allows (512 VGPRs per SIMD lane, allocation granule 8), and the instruction mix of its innermost loops (MFMA,
 LDS, global / buffer memory, VALU, SALU, waits, barriers) together with two patterns that cost time on CDNA4 and are easy to
-write by accident: IEEE divisions (v_div_fixup_f32) and a load immediately followed by `s_waitcnt vmcnt(0)` inside a loop (a
-dependent memory round trip per iteration). usage: tools/isa_audit.py [file.hip ...] > profiles/rNN_isa_audit.txt"""
+write by accident: IEEE divisions (v_div_fixup_f32), a load immediately followed by `s_waitcnt vmcnt(0)` inside a loop (a
+dependent memory round trip per iteration: "dep"), and loops with several FULL waits for their loads (branches around loads make
+the compiler wait for everything in flight at every use: "FULL-WAITS"). usage: tools/isa_audit.py [file.hip ...] > profiles/rNN_isa_audit.txt"""
 import glob
 import os
 import re
@@ -105,7 +106,9 @@ def audit(path):
                 k = classify(a.split()[0])
                 mix[k] = mix.get(k, 0) + 1
             dep = sum(1 for a, b in zip(ll, ll[1:]) if a.startswith(("buffer_load", "global_load")) and b.startswith("s_waitcnt vmcnt(0)"))
-            return (len(ll), mix, dep)
+            full = sum(1 for a in ll if a.startswith("s_waitcnt vmcnt(0)"))
+            loads = sum(1 for a in ll if a.startswith(("buffer_load", "global_load")))
+            return (len(ll), mix, dep, full, loads)
         loops = [summarise(ll) for ll in loops]
         loops.sort(key=lambda t: -t[0])
         granule = (md["vgpr"] + 7) // 8 * 8              # (.vgpr_count is the unified total on gfx90a+: arch VGPRs + AGPRs)
@@ -118,17 +121,18 @@ def main():
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     print("# tools/isa_audit.py -- hipcc --offload-arch=gfx950 -O3 of yolov5m_amd/csrc at HEAD (static: no GPU involved)")
     print("# per kernel: VGPRs (of which AGPRs) / SGPRs, spills (v/s), scratch B, static LDS B, waves per SIMD by registers, instructions;")
-    print("# then its one or two largest innermost loops: instruction count and mix, `dep` = loads directly followed by s_waitcnt vmcnt(0)")
+    print("# then its one or two largest loops: instruction count and mix (STATIC: both sides of every branch), `dep` = loads directly followed by")
+    print("# s_waitcnt vmcnt(0), FULL-WAITS = s_waitcnt vmcnt(0) count when the loop holds >= 4 loads and >= 2 of them")
     for f in files:
         print(f"\n## {os.path.basename(f)}")
         for name, md, waves, nops, tot, loops, ndiv in audit(f):
             short = re.sub(r"\(.*", "", name)[:86]
             print(f"{short:86s} v{md['vgpr']:3d}(a{md['agpr']:<3d}) s{md['sgpr']:3d} spill {md['vspill']}/{md['sspill']} scratch {md['scratch']:4d} "
                   f"lds {md['lds']:6d} waves/SIMD {waves} instr {nops:5d}" + (f" IEEE-div {ndiv}" if ndiv else ""))
-            for n_, mix, dep in loops:
+            for n_, mix, dep, full, loads in loops:
                 if n_ >= 24:
                     print("    loop %4d: " % n_ + " ".join(f"{k} {mix[k]}" for k in ("mfma", "lds", "vmem", "valu", "salu", "wait", "barrier") if k in mix)
-                          + (f"  dep {dep}" if dep else ""))
+                          + (f"  dep {dep}" if dep else "") + (f"  FULL-WAITS {full} for {loads} loads" if (full >= 2 and loads >= 4) else ""))
 
 
 if __name__ == "__main__":
