@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B of the four kernel changes of round 4 -- made WITHOUT a GPU, from the static ISA audit (tools/isa_audit.py) and verified on the CPU
+# A/B of the five kernel changes of round 4 -- made WITHOUT a GPU, from the static ISA audit (tools/isa_audit.py) and verified on the CPU
 # executor only -- against their round-3 forms, alone on the chip and inside the replayed step:
 #   wgrad_rows_kernel  per-run address arithmetic on the scalar unit          (400 -> 253 / 399 -> 346 instructions per chunk)
 #   bn_act_kernel      residual rows loaded raw: no vmcnt(0) per row            (428 -> 373, 120 -> 104 VGPRs)
 #   bwd_stem_kernel    straight-line streaming loop: counted waits              (904 -> 703, 21 -> 0 full waits per chunk)
 #   bwd_pw_kernel      unconditional re-requests: vmcnt(6) instead of vmcnt(0)  (725 -> 557 for C = 96)
+#   bn_bwd_reduce      act as a template parameter, raw loads pinned together   (636 -> 404, 128 -> 109 VGPRs; in the "bnact" = y5m_nn.hip variant)
 # One experiment library per kernel (that file taken from commit 746228a = end of round 3, everything else HEAD) + one with all four.
 # `tools/ab_r4_kernels.sh build` on the CPU box builds them into build/exp/ so that they travel with the snapshot.
 cd ${GRAFT_REPO_ROOT:-.}

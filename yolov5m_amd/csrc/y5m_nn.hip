@@ -660,11 +660,11 @@ extern "C" int y5m_bn_act_fused(const void* y, int ldy, const double* acc, int l
 #endif
 // accum != NULL: the block partials are ADDED into the accumulator rows accum[BNF_SLOTS][2][C] (y5m_bnfuse.h) instead of
 // being stored as partial rows
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                            int ldy, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
-                                                           int64_t M, int C, int CG, int RP, int act, float* __restrict__ part,
+                                                           int64_t M, int C, int CG, int RP, float* __restrict__ part,
                                                            double* __restrict__ accum) {
     __shared__ float sm[2][BNR_THREADS][9];    // [which][thread][k] (+1: the 8-float rows land on distinct banks)
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
@@ -681,20 +681,29 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
         const int64_t stride = (int64_t)gridDim.x * RP;
         int64_t m = (int64_t)blockIdx.x * RP + rl;
         for (; m + 3 * stride < M; m += 4 * stride) {
-            float g[4][8], yv[4][8];
+            // the eight 16-byte loads of four rows are issued together and kept RAW (32 registers instead of 64 unpacked floats:
+            // four waves per SIMD); a row is unpacked where it is consumed. SILU is a template parameter: the per-element test of
+            // `act` was 32 uniform branches + their mask arithmetic per iteration (636 -> ~400 instructions, tools/isa_audit.py);
+            // without the scheduling barrier the compiler sinks every load in front of its first use (load, vmcnt(0), compute, ...)
+            Raw8<T> rg[4], ry[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                load8<T>(dz + (m + u * stride) * lddz + c, g[u]);
-                load8<T>(y + (m + u * stride) * ldy + c, yv[u]);
+                raw_load8(dz + (m + u * stride) * lddz + c, rg[u]);
+                raw_load8(y + (m + u * stride) * ldy + c, ry[u]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                float g[8], yv[8];
+                raw_unpack8(rg[u], g);
+                raw_unpack8(ry[u], yv);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float dt = act == Y5M_ACT_SILU ? g[u][k] * silu_grad(yv[u][k] * sc[k] + sh[k]) : g[u][k];
+                    const float dt = SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
                     s1[k] += dt;
-                    s2[k] += dt * (yv[u][k] - mu[k]);
+                    s2[k] += dt * (yv[k] - mu[k]);
                 }
+            }
         }
         for (; m < M; m += stride) {
             float g[8], yv[8];
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
             load8<T>(y + m * ldy + c, yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float dt = act == Y5M_ACT_SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
+                const float dt = SILU ? g[k] * silu_grad(yv[k] * sc[k] + sh[k]) : g[k];
                 s1[k] += dt;
                 s2[k] += dt * (yv[k] - mu[k]);
             }
@@ -848,9 +857,11 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     float* stage = reinterpret_cast<float*>(w);
     hipStream_t st = y5m_stream(stream);
     const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);   // (swept 256..2048 in the full step: 512 is best)
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st,
-                                         (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, gr.CG, gr.RP, act, part,
-                                         (double*)nullptr);)
+    DISPATCH_T(dtype, {
+        auto kern = act == Y5M_ACT_SILU ? bn_bwd_reduce_kernel<T, true> : bn_bwd_reduce_kernel<T, false>;
+        hipLaunchKernelGGL(kern, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st, (const T*)dz, lddz, (const T*)y, ldy,
+                           scale, shift, mean, M, C, gr.CG, gr.RP, part, (double*)nullptr);
+    })
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     BnFinArgs F{};
     BnBwdFinArgs G{scale, mean, invstd, 1.0f / (float)M, cB, cD, dgamma, dbeta, accumulate_param_grads, 1};
@@ -879,9 +890,11 @@ extern "C" int y5m_bn_bwd_fused_phase(const void* dz, int lddz, const void* y, i
         static int rgx = -1;                   // Y5M_BNR_GX: workgroups of the reduce pass (no partial rows to pay for here)
         if (rgx < 0) { const char* e = getenv("Y5M_BNR_GX"); rgx = e ? atoi(e) : BNR_MAX_GX; }
         const EwGeom grr = ew_geom(M, C / 8, rgx, BNR_THREADS);
-        DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(grr.gx, (unsigned)grr.groups), dim3(BNR_THREADS), 0, st,
-                                             (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, M, C, grr.CG, grr.RP, act,
-                                             (float*)nullptr, acc);)
+        DISPATCH_T(dtype, {
+            auto kern = act == Y5M_ACT_SILU ? bn_bwd_reduce_kernel<T, true> : bn_bwd_reduce_kernel<T, false>;
+            hipLaunchKernelGGL(kern, dim3(grr.gx, (unsigned)grr.groups), dim3(BNR_THREADS), 0, st, (const T*)dz, lddz, (const T*)y,
+                               ldy, scale, shift, mean, M, C, grr.CG, grr.RP, (float*)nullptr, acc);
+        })
         Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     }
     if (phase & 2) {
