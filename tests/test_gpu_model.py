@@ -966,6 +966,31 @@ def test_native_gradient_accumulation_matches_torch(use_graph):
     assert bool(torch.isfinite(m2.flat_params).all()) and not torch.equal(m2.flat_params.cpu(), torch.from_numpy(p2))
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_accumulation_path_sees_a_changed_learning_rate(use_graph):
+    """with accumulate > 1 the captured optimizer graph bakes lr / betas / weight decay in as kernel arguments; a
+    change of `step.lr` must drop it (NativeTrainStep._check_hyper runs on the accumulation path and in flush() too). lr = 0
+    after one optimizer step: the parameters must stay exactly where they are -- a stale graph would move them."""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    x = synth_images(2, 64, 64, seed="acclr").to(DEV)
+    t = synth_labels(2, 4, seed="acclrl")
+    m = _model("bf16"); m.train()
+    step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, accumulate=2, use_graph=use_graph)
+    p0 = m.flat_params.clone()
+    for _ in range(4):                                   # two optimizer steps (the second one through the captured graphs)
+        step.step(x, t)
+    torch.cuda.synchronize()
+    p1 = m.flat_params.clone()
+    assert not torch.equal(p1, p0)
+    step.lr = 0.0
+    for _ in range(4):
+        step.step(x, t)
+    step.step(x, t); step.flush()                        # and a partial accumulation flushed
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params, p1), float((m.flat_params - p1).abs().max())
+
+
 def test_native_optimizer_state_is_torch_adam_state():
     """checkpoint interop (reference utils/utils.py:56-82): after two native steps the exported optimizer state
     loads into torch.optim.Adam and the THIRD step taken by torch equals the third native step; and the
