@@ -102,6 +102,43 @@ def test_per_layer_backward_helper_of_the_full_size_gpu_test(monkeypatch):
     assert any(n.startswith("wgrad_rows_kernel") for n in names) and any(n.startswith("conv_halo_kernel<6,3>") for n in names), names
 
 
+_SLAB_CHILD = r"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from emu.harness import emulated
+from yolov5m_amd import config
+from yolov5m_amd.model import YOLOV5m
+from yolov5m_amd.utils.synth import synth_images, synth_state_dict
+with emulated():
+    m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+    m.load_state_dict(synth_state_dict(), strict=True)
+    m.compute_dtype = "bf16"; m.eval()
+    with torch.no_grad():
+        o = m(synth_images(5, 64, 96, seed="slab"))
+    np.savez(sys.argv[1], *[t.numpy() for t in o])
+"""
+
+
+def test_conv_slab_path_equals_one_launch(tmp_path):
+    """BASELINE.json configs[4] runs every layer whose input view exceeds 2 GiB in slabs of whole images (y5m_conv); the only
+    GPU test of that loop needs B = 128 @ 1280x1280. Y5M_CONV_SLAB_BYTES lowers the limit (read once: child processes): the
+    eval forward of 5 images with a 40 KB limit -- one to three images per slab depending on the layer, a ragged last slab,
+    residual and head epilogues included -- equals the one-launch forward bit for bit."""
+    import subprocess
+    import numpy as np
+    root = os.path.dirname(HERE)
+    outs = []
+    for tag, env in (("one", {}), ("slabs", {"Y5M_CONV_SLAB_BYTES": "40960"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _SLAB_CHILD % (root, HERE), f], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0
+
+
 def test_plan_cache_retries_after_oom_outside_the_handler(monkeypatch):
     """the retry after an out-of-memory plan build must run AFTER the except block (the traceback keeps the failed
     plan alive inside it), with every resident plan released first"""
