@@ -601,6 +601,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
 extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldres,
                           void* out, int ldout, int64_t M, int C, int act, int dtype, void* stream) {
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    Y5M_REQUIRE(!res || (ldres % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0 && (dtype != Y5M_BF16 || ldres % 8 == 0)),
+                "res: 16-byte aligned rows (the residual is read in 16-byte pieces)");
     const EwGeom g = ew_geom(M, C / 8, 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
                                          (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act,
@@ -631,6 +633,8 @@ extern "C" int y5m_bn_act_fused(const void* y, int ldy, const double* acc, int l
     Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     Y5M_REQUIRE(acc && gamma && beta && scale && shift && mean_out && invstd_out, "null pointer");
     Y5M_REQUIRE(!update_running || (running_mean && running_var), "running statistics missing");
+    Y5M_REQUIRE(!res || (ldres % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0 && (dtype != Y5M_BF16 || ldres % 8 == 0)),
+                "res: 16-byte aligned rows (the residual is read in 16-byte pieces)");
     // (every workgroup pays the coefficient prologue, so fewer, longer workgroups than the plain form: 4096 / 2048 / 1536 /
     //  1024 = 27.44 / 27.24 / 27.14 / 27.3 ms per step, B=64 @ 640^2; the plain form wants 4096)
     const EwGeom g = ew_geom(M, C / 8, BNF_EW_GX);
