@@ -28,10 +28,11 @@ from .. import _lib, config
 # GPU ("Memory access fault ... Reason: Unknown") -- the round-2 "graph replay fault". tools/graph_first_replay.py
 # reproduces it within seconds (5 rounds x 15 captured plans: 3 of 3 runs clean with the graphs kept, every run dead without);
 # linear graphs (Y5M_OVERLAP=0) are destroyed cleanly (120 create / destroy cycles). So: a forked graph gets one extra
-# reference that nobody drops (it is not destroyed at interpreter shutdown either), and once Y5M_GRAPH_KEEP_MAX (64) of them
-# exist further plans are captured LINEARLY (weight gradients inline, ~5 % slower per step) so that a long multi_scale run
+# reference that nobody drops (it is not destroyed at interpreter shutdown either), and once the graphs of Y5M_GRAPH_KEEP_MAX
+# (64) captured PLANS are being kept, further plans are captured LINEARLY (weight gradients inline, ~5 % slower per step) so that a long multi_scale run
 # which keeps evicting and re-capturing its largest plans cannot leak without bound. NOTES.md has the hunt.
 _KEPT_GRAPHS = []
+_KEPT_PLANS = 0                  # captures (plans) that keep forked graphs: the cap counts these, not the 1-5 graphs of a plan
 _WARNED_LINEAR = False
 
 
@@ -45,13 +46,16 @@ def _keep_forever(g):
 def _forked_capture_allowed():
     """False once Y5M_GRAPH_KEEP_MAX forked graphs are being kept alive: further plans are captured linearly. Says so once --
     a long multi_scale / data-parallel run that reaches the cap runs its re-captured sizes ~5 % slower from then on."""
-    global _WARNED_LINEAR
-    ok = len(_KEPT_GRAPHS) < int(os.environ.get("Y5M_GRAPH_KEEP_MAX", "64"))
-    if not ok and not _WARNED_LINEAR:
+    global _WARNED_LINEAR, _KEPT_PLANS
+    ok = _KEPT_PLANS < int(os.environ.get("Y5M_GRAPH_KEEP_MAX", "64"))
+    if ok:
+        _KEPT_PLANS += 1         # (the caller captures one plan: a whole-step graph, or one graph per backward segment)
+    elif not _WARNED_LINEAR:
         _WARNED_LINEAR = True
         import warnings
-        warnings.warn(f"{len(_KEPT_GRAPHS)} captured graphs with forked branches are being kept alive (Y5M_GRAPH_KEEP_MAX): "
-                      "plans captured from now on run their weight gradients inline (about 5 % slower per step)")
+        warnings.warn(f"the captured graphs of {_KEPT_PLANS} plans ({len(_KEPT_GRAPHS)} graphs with forked branches) are being kept "
+                      "alive (Y5M_GRAPH_KEEP_MAX): plans captured from now on run their weight gradients inline (about 5 % "
+                      "slower per step)")
     return ok
 
 
