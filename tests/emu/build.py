@@ -49,8 +49,10 @@ def build(verbose=False):
              os.path.join(HERE, "include", "hip", "hip_runtime.h")])
     stamp = os.path.join(OUT_DIR, "stamp")
     dig = _digest(deps)
-    if os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
-        return LIB
+    if os.path.exists(LIB) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read() == dig:
+                return LIB
 
     def one(name):
         src = os.path.join(CSRC, name)

@@ -4,8 +4,13 @@
 for x86-64, every GPU thread a fiber -- and lets host tensors through the wrappers' device checks, so that the product's own
 Python (ops.py, engine.py, NativeTrainStep, parallel.py) drives the product's own kernel code on this CPU-only container.
 Nothing in yolov5m_amd/ knows about it: outside this context manager the package has no CPU path and refuses host tensors
-(tests/test_abi.py). Streams, events and graphs do not exist here (launches are synchronous): plans run with Y5M_OVERLAP=0
-and use_graph=False, so stream ordering is NOT what these tests cover -- that is the -m gpu suite's job."""
+(tests/test_abi.py). Streams and events do not exist here (launches are synchronous, plans run with Y5M_OVERLAP=0), so stream
+ordering is NOT what these tests cover -- that is the -m gpu suite's job.
+
+Captured graphs DO exist, as a recording: inside `with torch.cuda.graph(g):` every launching C-ABI call (last argument = stream)
+is appended to g instead of executed, and so is every in-place torch op (fills, the step counter) through a TorchDispatchMode;
+`g.replay()` runs the list. An op that would ALLOCATE inside a capture raises -- the rule a real capture imposes. That puts the
+graph bookkeeping of NativeTrainStep (one graph per plan, segments, eviction, _check_hyper, accumulation) under test on a CPU."""
 import contextlib
 import ctypes
 import os
@@ -16,6 +21,71 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
+
+
+_REC = []                 # stack of op lists being recorded (innermost capture last)
+_QUERY = ("workspace_bytes", "eligible", "kernel_name", "owner_ptrs", "_is_", "tile_n", "stats_rows", "stages_stats", "acc_slots",
+          "fuse_enabled", "persistent_cu", "device_ok", "last_error", "version")
+
+
+class _LibProxy:
+    """the ctypes handle, with every LAUNCHING entry point (signature ends with the stream) recordable"""
+
+    def __init__(self, L, sigs):
+        self._L, self._w = L, {}
+        self._launching = {n for n, (res, args) in sigs.items() if args and args[-1] is ctypes.c_void_p and not any(q in n for q in _QUERY)}
+
+    def __getattr__(self, name):
+        w = self._w.get(name)
+        if w is None:
+            fn = getattr(self._L, name)
+            if name in self._launching:
+                def w(*a, _fn=fn):
+                    if _REC:
+                        _REC[-1].append((_fn, a, None))
+                        return 0
+                    return _fn(*a)
+            else:
+                w = fn
+            self._w[name] = w
+        return w
+
+
+class FakeGraph:
+    """stand-in of torch.cuda.CUDAGraph: the recorded launches and in-place torch ops of one capture"""
+
+    def __init__(self):
+        self.ops = []
+
+    def replay(self):
+        for fn, a, kw in self.ops:
+            fn(*a) if kw is None else fn(*a, **kw)
+
+    def reset(self):
+        self.ops = []
+
+
+@contextlib.contextmanager
+def fake_capture(g, *a, **k):
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class Rec(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            name = func._schema.name.split("::")[1]
+            if name.endswith("_"):
+                g.ops.append((func, args, kwargs))
+                return args[0]
+            if name in ("select", "slice", "view", "reshape", "as_strided", "detach", "alias", "expand", "unsqueeze", "squeeze",
+                        "_unsafe_view", "permute", "transpose", "t", "narrow", "unbind", "split", "_local_scalar_dense", "item"):
+                return func(*args, **kwargs)            # views / host reads of existing tensors: no allocation
+            raise RuntimeError(f"capture: aten::{name} inside a captured region (it would allocate, or is not replayable)")
+    _REC.append(g.ops)
+    try:
+        with Rec():
+            yield g
+    finally:
+        _REC.pop()
 
 
 def emu_lib_path():
@@ -36,7 +106,8 @@ def emulated(cus=None):
     for name, (res, args) in list(_lib._SIGS.items()):
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
-    saved = dict(lib=_lib._lib, stream_ptr=_lib.stream_ptr, require_cuda=_lib.require_cuda,
+    L = _LibProxy(L, _lib._SIGS)
+    saved = dict(lib=_lib._lib, stream_ptr=_lib.stream_ptr, require_cuda=_lib.require_cuda, graph=torch.cuda.graph, cgraph=torch.cuda.CUDAGraph,
                  require_cuda_device=getattr(_lib, "require_cuda_device", None),
                  sync=torch.cuda.synchronize, mem=torch.cuda.memory_allocated, props=torch.cuda.get_device_properties,
                  zero=dict(_lib._zero_pages))
@@ -47,6 +118,7 @@ def emulated(cus=None):
     _lib.require_cuda_device = lambda dev: None
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.memory_allocated = lambda *a, **k: 0
+    torch.cuda.CUDAGraph, torch.cuda.graph = FakeGraph, fake_capture
 
     class _Props:
         total_memory = 64 << 30
@@ -60,6 +132,7 @@ def emulated(cus=None):
         if saved["require_cuda_device"] is not None:
             _lib.require_cuda_device = saved["require_cuda_device"]
         torch.cuda.synchronize, torch.cuda.memory_allocated = saved["sync"], saved["mem"]
+        torch.cuda.CUDAGraph, torch.cuda.graph = saved["cgraph"], saved["graph"]
         torch.cuda.get_device_properties = saved["props"]
         for k, v in saved_env.items():
             if v is None:

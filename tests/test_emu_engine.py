@@ -190,11 +190,17 @@ def _dp_worker(rank, world, port, q):
             m = _model()
             parallel.broadcast_parameters(m)
             hook = parallel.GradAllReduce(world)
-            step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=False, grad_hook=hook, overlap=True)
+            # use_graph=True: the harness records the per-segment captures, the second step REPLAYS them with a bucket behind each
+            step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=True, grad_hook=hook, overlap=True)
             p0 = m.flat_params.clone()
             step.step(x, t)
+            segs = step._fb_graphs[next(iter(step._fb_graphs))]
+            assert segs[2] == "segments" and len(segs[1]) == 3 and all(len(g.ops) > 0 for g in segs[1]) and len(step._opt_graph.ops) == 3
             cuts = m._engines[next(iter(m._engines))]._cuts
             gerr = float((m.flat_grads - ref).abs().max() / ref.abs().max())
+            p1 = m.flat_params.clone()
+            step.step(x, t)                                  # replayed segments
+            assert float((m.flat_params - p1).abs().max()) > 0 and int(step.d_step) == 2
             mine = m.flat_params.clone()
             others = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(others, mine)

@@ -10,7 +10,7 @@ Y5M_DIST_BACKEND: gloo lets both ranks share one GPU, nccl = RCCL needs one GPU 
      of both schedules to 2e-2; that bound sits inside its own noise -- profiles/r04_adam_noise_emu.txt: a gradient noise of
      2e-7 already moves the 4-step update by 2.5e-3, Adam's first updates being +-lr whatever the gradient's size -- and was
      the likely source of round 3's one-in-ten red run. It is still printed, with a bound only a gross error reaches.)
-Y5M_DP_EMU=1 runs the script's logic on the CPU lane-level executor of tests/emu (host tensors, no graphs, Y5M_DP_SHAPE=B,H,W)."""
+Y5M_DP_EMU=1 runs the script's logic on the CPU lane-level executor of tests/emu (host tensors, recorded graphs, Y5M_DP_SHAPE=B,H,W)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,7 +32,7 @@ from yolov5m_amd.utils.synth import synth_images, synth_labels, synth_state_dict
 rank, local, world = parallel.init_from_env(backend="gloo" if EMU else None)
 assert world > 1, "run under torch.distributed.run with --nproc-per-node >= 2"
 dev = "cpu" if EMU else f"cuda:{torch.cuda.current_device()}"
-GRAPH = not EMU
+GRAPH = True                     # (on the CPU executor the harness records captures: tests/emu/harness.py)
 SHAPE = tuple(int(v) for v in os.environ.get("Y5M_DP_SHAPE", "2,96,128").split(","))
 FAILED = []
 
