@@ -56,7 +56,6 @@ SELECT = {
         "test_sppf_pool_forward_backward_bit_exact": lambda kw: True,
         "test_submodule_forward_matches_torch": lambda kw: True,
         "test_submodule_backward_matches_torch": lambda kw: True,
-        "test_native_train_step_graph_replay_bf16": lambda kw: True,      # (captured graphs = the harness's recordings)
         "test_eval_merged_c3_pair_equals_two_convs": lambda kw: kw["dtype"] == "bf16",
         # (test_native_train_step_matches_torch_adam / test_input_stage_u8_golden bound rounding-level noise -- 8 near-cancelling
         #  Adam elements of 21 M, 2e-6 absolute -- that the host's un-contracted arithmetic moves: 12 elements / 2.1e-6 here)
