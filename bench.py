@@ -218,6 +218,122 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5):
                         f"(obj ~ N(-5,2^2)), max_detections 300 (BASELINE.json configs[4])", "unit": "boxes/s", **out}
 
 
+def _guarded(name, fn):
+    """an untimed leg must never cost the JSON line: a Python error in it becomes {"error": ...} (traceback on stderr)"""
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        return {"error": f"{name} leg failed: {type(e).__name__}: {str(e)[:300]}"}
+
+
+def roofline_leg(step, model, images, targets, dtype):
+    """rank 0, outside the timed region: HIP-event pairs around every launch of the step (profile_step) -> the `roofline` object"""
+    fams = {}
+    cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0], "fused_pw_bwd": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
+    esz = 2 if dtype == "bf16" else 4
+    kernels, insitu = {}, {}
+    for _ in range(2):
+        # the step's OWN schedule (weight gradients on the forked stream next to the main stream's kernels), every
+        # launch timed by HIP events on the stream it runs on: what a launch costs inside the step
+        _f, _c, kern = step.profile_step(images, targets, detail="kernels", overlapped=True)
+        for name, ms_, fl, *by in kern:
+            k = insitu.setdefault(name, [0.0, 0.0, 0, 0.0])
+            k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
+    for _ in range(2):
+        # the same launches with the forked stream serialised: per-family times that add up
+        fam, convs, kern = step.profile_step(images, targets, detail="kernels")
+        for name, ms_, fl, *by in kern:
+            k = kernels.setdefault(name, [0.0, 0.0, 0, 0.0])
+            k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
+        for k, (m_, n_) in fam.items():
+            a, b = fams.get(k, (0.0, 0))
+            fams[k] = (a + m_, b + n_)
+        for ms_, a in convs:
+            c = cls["pointwise" if a.th * a.tw == 1 else "spatial"]
+            c[0] += ms_
+            c[1] += 2.0 * a.M * a.N * a.K
+            c[2] += float(a.M) * (a.K / (a.th * a.tw) + a.N) * esz + float(a.N) * a.K * esz
+            c[3] += 1
+        for ms_, a in step.last_bwd_pw:
+            # fused pointwise backward: algorithmic bytes = dz + y (N channels each) + x + dx (C channels each; + the
+            # accumulation source when dx is added onto a tensor), 2 bytes per element
+            c = cls["fused_pw_bwd"]
+            c[0] += ms_
+            c[1] += 4.0 * a.M * a.N * a.C
+            c[2] += float(a.M) * (2 * a.N + (3 if (a.accumulate or a.res) else 2) * a.C) * esz
+            c[3] += 1
+    eng = model._engine_for(images)
+    fwd_flops = eng.conv_flops()
+    stem = eng.layers[0]
+    dgrad_flops = fwd_flops - 2 * stem.M * stem.cout * stem.cin_real * stem.k * stem.k
+    conv_ms, conv_n = fams.get("conv_igemm", (0.0, 1))
+    conv_ms /= 2
+    conv_n //= 2
+    achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
+    wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
+    # headline = the ONE kernel instantiation with the largest share of the step, by summed launch time INSIDE the
+    # step's own overlapped schedule (HIP events on the launching stream); `frac` is that in-situ figure, the
+    # serialised one (forked stream run inline) sits beside it; the conv family and the per-kernel table follow
+    ranked = sorted(insitu.items(), key=lambda kv: -kv[1][0])
+    dom_name, (dom_ms, dom_fl, dom_n, dom_by) = ranked[0]
+    ser_ms, ser_fl, ser_n, ser_by = kernels.get(dom_name, (dom_ms, dom_fl, dom_n, dom_by))
+    hbm = dom_by > 0            # a kernel that carries algorithmic BYTES (the fused pointwise backward) is HBM-bound
+    if hbm:
+        dom_ach, ser_ach, peak, unit = dom_by / (dom_ms * 1e-3) / 1e9, ser_by / (ser_ms * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
+    else:
+        dom_ach, ser_ach, peak, unit = dom_fl / (dom_ms * 1e-3) / 1e12, ser_fl / (ser_ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
+    traffic, traffic_src = pmc_traffic(dom_name)
+
+    def row(n_, v):
+        r_ = {"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
+              "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+              "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+              "ms_per_step_serialised": round(kernels.get(n_, v)[0] / 2, 3)}
+        if v[3] > 0:
+            r_.update(bound="hbm", achieved_GBps=round(v[3] / (v[0] * 1e-3) / 1e9, 1),
+                      frac=round(v[3] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4))
+        return r_
+    return {
+        "bound": "hbm" if hbm else "mfma", "kernel": dom_name,
+        "achieved": round(dom_ach, 2), "peak": peak, "unit": unit,
+        "frac": round(dom_ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "timing": "HIP events around every launch on its own stream, inside the step's overlapped schedule (eager pass)",
+        "launches_per_step": dom_n // 2, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
+        "algorithmic_gflop_per_launch": round(dom_fl / max(dom_n, 1) / 1e9, 2),
+        "algorithmic_MB_per_launch": round(dom_by / max(dom_n, 1) / 1e6, 2) if hbm else None,
+        "share_of_step_ms": round(dom_ms / 2, 3),
+        "achieved_serialised": round(ser_ach, 2), "frac_serialised": round(ser_ach / peak, 4),
+        "avg_launch_us_serialised": round(ser_ms * 1e3 / max(ser_n, 1), 2),
+        "by_kernel": [row(n_, v) for n_, v in ranked[:8]],
+        "conv_family": {"what": "forward conv + data gradient, all y5m_conv launches of one step",
+                        "achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                        "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
+                        "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1)},
+        "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
+        "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
+        # the same launches split by what bounds them: k x k taps (MFMA) vs 1x1 (HBM: every input and output
+        # element moves once, M*(Cin+Cout) elements + the weights)
+        "by_class": {
+            "spatial_convs(taps>1)": {"bound": "mfma", "launches_per_step": cls["spatial"][3] // 2,
+                                      "ms_per_step": round(cls["spatial"][0] / 2, 3),
+                                      "achieved_TFLOPs": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9, 1),
+                                      "frac": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)},
+            "pointwise_convs(1x1)": {"bound": "hbm", "launches_per_step": cls["pointwise"][3] // 2,
+                                     "ms_per_step": round(cls["pointwise"][0] / 2, 3),
+                                     "achieved_GBps": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6, 1),
+                                     "achieved_TFLOPs": round(cls["pointwise"][1] / max(cls["pointwise"][0], 1e-9) / 1e9, 1),
+                                     "frac": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
+            "fused_pointwise_backward(bn apply + dgrad + wgrad)": {
+                "bound": "hbm", "launches_per_step": cls["fused_pw_bwd"][3] // 2, "ms_per_step": round(cls["fused_pw_bwd"][0] / 2, 3),
+                "achieved_GBps": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6, 1),
+                "achieved_TFLOPs": round(cls["fused_pw_bwd"][1] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e9, 1),
+                "frac": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
+        },
+    }
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -270,6 +386,12 @@ def main():
     from yolov5m_amd.utils.synth import synth_images, synth_labels
 
     rank, local, world = parallel.init_from_env()
+    # rank 0 runs the untimed legs (roofline, cpu_baseline) alone while the other ranks wait: they wait on a gloo group with a
+    # two-hour timeout, not in an RCCL barrier whose watchdog would tear the job down after the process group's default timeout
+    exit_group = None
+    if world > 1:
+        import datetime
+        exit_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
     backend = dist.get_backend() if world > 1 else None
@@ -357,7 +479,7 @@ def main():
     # same invocation, so that an N-GPU record carries overlapped and plain step times side by side
     plain = None
     if world > 1 and not args.no_overlap:
-        hook2 = parallel.GradAllReduce(world, timing=False)
+        hook2 = parallel.GradAllReduce(world, timing=True)          # (same event pairs as the overlapped leg)
         step2 = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook2, overlap=False)
         for _ in range(2):
             step2.step(images, targets)
@@ -373,7 +495,7 @@ def main():
 
     if rank != 0:
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=exit_group)
         return
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -384,11 +506,16 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"YOLOv5m full train step (fwd + ComputeLoss + bwd + clip + Adam), batch {B}/GPU @ "
-                               f"{S}x{S}, random-init weights, 8 boxes/image (BASELINE.json configs[2]"
-                               + ("/[3]" if world > 1 else "") + ")",
+                               f"{S}x{S}, random-init weights, 8 boxes/image"
+                               + ((" (BASELINE.json configs[2]" + ("/[3]" if world > 1 else "") + ")") if (B, S) == (64, 640)
+                                  else " (NOT a BASELINE.json configuration: --batch / --size given)"),
                    "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph, **first_loss_check(first_loss, B, S, rank),
                    "final_loss": round(final_loss, 4)},
     }
+    r4 = int(os.environ.get("Y5M_R4_KERNELS", "0") or 0) & 31
+    out["kernel_forms"] = {"Y5M_R4_KERNELS": r4,
+                           "note": "bit mask of the round-4 kernel rewrites in use (1 wgrad_rows, 2 bn_act, 4 bwd_stem, 8 bwd_pw, "
+                                   "16 bn_bwd_reduce); 0 = the round-3 forms, the ones that passed the GPU suite on hardware"}
     if world > 1:
         out["exchange"] = {"what": "SUM all-reduce of the flat f32 gradient buffer (84.8 MB), "
                                    + ("one message after the backward pass" if args.no_overlap else
@@ -397,124 +524,25 @@ def main():
                            "last_step_max_over_ranks": xstats,
                            # (what the exposed time should be on xGMI)
                            "plain_exchange_same_run": plain,
-                           "overlap_gain_ms_per_step": round(plain["ms_per_step"] - ms, 3) if plain else None}
+                           # approximate: 5 plain steps against args.steps overlapped ones, a second NativeTrainStep (fresh Adam
+                           # state, its own captured graphs) on the same model
+                           "overlap_gain_ms_per_step_approx": round(plain["ms_per_step"] - ms, 3) if plain else None}
     if not args.no_roofline:
-        fams = {}
-        cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0], "fused_pw_bwd": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
-        esz = 2 if args.dtype == "bf16" else 4
-        kernels, insitu = {}, {}
-        for _ in range(2):
-            # the step's OWN schedule (weight gradients on the forked stream next to the main stream's kernels), every
-            # launch timed by HIP events on the stream it runs on: what a launch costs inside the step
-            _f, _c, kern = step.profile_step(images, targets, detail="kernels", overlapped=True)
-            for name, ms_, fl, *by in kern:
-                k = insitu.setdefault(name, [0.0, 0.0, 0, 0.0])
-                k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
-        for _ in range(2):
-            # the same launches with the forked stream serialised: per-family times that add up
-            fam, convs, kern = step.profile_step(images, targets, detail="kernels")
-            for name, ms_, fl, *by in kern:
-                k = kernels.setdefault(name, [0.0, 0.0, 0, 0.0])
-                k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
-            for k, (m_, n_) in fam.items():
-                a, b = fams.get(k, (0.0, 0))
-                fams[k] = (a + m_, b + n_)
-            for ms_, a in convs:
-                c = cls["pointwise" if a.th * a.tw == 1 else "spatial"]
-                c[0] += ms_
-                c[1] += 2.0 * a.M * a.N * a.K
-                c[2] += float(a.M) * (a.K / (a.th * a.tw) + a.N) * esz + float(a.N) * a.K * esz
-                c[3] += 1
-            for ms_, a in step.last_bwd_pw:
-                # fused pointwise backward: algorithmic bytes = dz + y (N channels each) + x + dx (C channels each; + the
-                # accumulation source when dx is added onto a tensor), 2 bytes per element
-                c = cls["fused_pw_bwd"]
-                c[0] += ms_
-                c[1] += 4.0 * a.M * a.N * a.C
-                c[2] += float(a.M) * (2 * a.N + (3 if (a.accumulate or a.res) else 2) * a.C) * esz
-                c[3] += 1
-        eng = model._engine_for(images)
-        fwd_flops = eng.conv_flops()
-        stem = eng.layers[0]
-        dgrad_flops = fwd_flops - 2 * stem.M * stem.cout * stem.cin_real * stem.k * stem.k
-        conv_ms, conv_n = fams.get("conv_igemm", (0.0, 1))
-        conv_ms /= 2
-        conv_n //= 2
-        achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
-        wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
-        # headline = the ONE kernel instantiation with the largest share of the step, by summed launch time INSIDE the
-        # step's own overlapped schedule (HIP events on the launching stream); `frac` is that in-situ figure, the
-        # serialised one (forked stream run inline) sits beside it; the conv family and the per-kernel table follow
-        ranked = sorted(insitu.items(), key=lambda kv: -kv[1][0])
-        dom_name, (dom_ms, dom_fl, dom_n, dom_by) = ranked[0]
-        ser_ms, ser_fl, ser_n, ser_by = kernels.get(dom_name, (dom_ms, dom_fl, dom_n, dom_by))
-        hbm = dom_by > 0            # a kernel that carries algorithmic BYTES (the fused pointwise backward) is HBM-bound
-        if hbm:
-            dom_ach, ser_ach, peak, unit = dom_by / (dom_ms * 1e-3) / 1e9, ser_by / (ser_ms * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
-        else:
-            dom_ach, ser_ach, peak, unit = dom_fl / (dom_ms * 1e-3) / 1e12, ser_fl / (ser_ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s"
-        traffic, traffic_src = pmc_traffic(dom_name)
-
-        def row(n_, v):
-            r_ = {"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
-                  "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
-                  "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                  "ms_per_step_serialised": round(kernels.get(n_, v)[0] / 2, 3)}
-            if v[3] > 0:
-                r_.update(bound="hbm", achieved_GBps=round(v[3] / (v[0] * 1e-3) / 1e9, 1),
-                          frac=round(v[3] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4))
-            return r_
-        out["roofline"] = {
-            "bound": "hbm" if hbm else "mfma", "kernel": dom_name,
-            "achieved": round(dom_ach, 2), "peak": peak, "unit": unit,
-            "frac": round(dom_ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "timing": "HIP events around every launch on its own stream, inside the step's overlapped schedule (eager pass)",
-            "launches_per_step": dom_n // 2, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
-            "algorithmic_gflop_per_launch": round(dom_fl / max(dom_n, 1) / 1e9, 2),
-            "algorithmic_MB_per_launch": round(dom_by / max(dom_n, 1) / 1e6, 2) if hbm else None,
-            "share_of_step_ms": round(dom_ms / 2, 3),
-            "achieved_serialised": round(ser_ach, 2), "frac_serialised": round(ser_ach / peak, 4),
-            "avg_launch_us_serialised": round(ser_ms * 1e3 / max(ser_n, 1), 2),
-            "by_kernel": [row(n_, v) for n_, v in ranked[:8]],
-            "conv_family": {"what": "forward conv + data gradient, all y5m_conv launches of one step",
-                            "achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                            "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
-                            "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1)},
-            "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
-            "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
-            # the same launches split by what bounds them: k x k taps (MFMA) vs 1x1 (HBM: every input and output
-            # element moves once, M*(Cin+Cout) elements + the weights)
-            "by_class": {
-                "spatial_convs(taps>1)": {"bound": "mfma", "launches_per_step": cls["spatial"][3] // 2,
-                                          "ms_per_step": round(cls["spatial"][0] / 2, 3),
-                                          "achieved_TFLOPs": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9, 1),
-                                          "frac": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)},
-                "pointwise_convs(1x1)": {"bound": "hbm", "launches_per_step": cls["pointwise"][3] // 2,
-                                         "ms_per_step": round(cls["pointwise"][0] / 2, 3),
-                                         "achieved_GBps": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6, 1),
-                                         "achieved_TFLOPs": round(cls["pointwise"][1] / max(cls["pointwise"][0], 1e-9) / 1e9, 1),
-                                         "frac": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
-                "fused_pointwise_backward(bn apply + dgrad + wgrad)": {
-                    "bound": "hbm", "launches_per_step": cls["fused_pw_bwd"][3] // 2, "ms_per_step": round(cls["fused_pw_bwd"][0] / 2, 3),
-                    "achieved_GBps": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6, 1),
-                    "achieved_TFLOPs": round(cls["fused_pw_bwd"][1] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e9, 1),
-                    "frac": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
-            },
-        }
+        out["roofline"] = _guarded("roofline", lambda: roofline_leg(step, model, images, targets, args.dtype))
     if world == 1 and not args.no_detect:
         del step, images
         model._engines = {}
         torch.cuda.empty_cache()
-        out["forward"] = forward_leg(model, dev)
+        out["forward"] = _guarded("forward", lambda: forward_leg(model, dev))
         model._engines = {}
         torch.cuda.empty_cache()
-        out["detect"] = detect_leg(dev, model)
+        out["detect"] = _guarded("detect", lambda: detect_leg(dev, model))
     if not args.no_cpu_baseline:
-        # (rank 0's host cores; with N > 1 the other ranks idle at the final barrier meanwhile)
-        out["cpu_baseline"] = cpu_baseline(world=world)
-    print(json.dumps(out))
+        # (rank 0's host cores; with N > 1 the other ranks wait at the exit barrier -- a gloo group with a two-hour timeout)
+        out["cpu_baseline"] = _guarded("cpu_baseline", lambda: cpu_baseline(world=world))
+    print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=exit_group)
 
 
 if __name__ == "__main__":

@@ -81,5 +81,37 @@ def build(verbose=False):
     return LIB
 
 
+def build_variant(tag, edits):
+    """build/emu/liby5m_emu_<tag>.so: the executor's library with some kernel sources EDITED (edits: {file name: function text ->
+    text}) -- the deliberately broken kernels of tests/test_emu_checks.py. Only the edited translation units are recompiled; the
+    rest are the objects of the regular build."""
+    build()
+    vdir = os.path.join(OUT_DIR, "variant_" + tag)
+    os.makedirs(vdir, exist_ok=True)
+    lib = os.path.join(OUT_DIR, f"liby5m_emu_{tag}.so")
+    objs = []
+    for name in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
+        if name not in edits:
+            objs.append(os.path.join(OUT_DIR, name.replace(".hip", ".o")))
+            continue
+        src = os.path.join(CSRC, name)
+        with open(src) as f:
+            text = f.read()
+        new = edits[name](text)
+        if new == text:
+            raise RuntimeError(f"variant {tag}: the edit of {name} changed nothing (the source has moved on: update the test)")
+        cpp = os.path.join(vdir, name.replace(".hip", ".cpp"))
+        with open(cpp, "w") as f:
+            f.write(f'#line 1 "{src}"\n' + translate(new, src))
+        obj = cpp[:-4] + ".o"
+        r = subprocess.run([CXX] + FLAGS + (["-ffp-contract=off"] if name in EXACT else []) + ["-c", cpp, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"emu variant build of {name} failed:\n{r.stderr[-4000:]}")
+        objs.append(obj)
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) +
+                          ["-o", lib] + objs + [os.path.join(OUT_DIR, "emu_rt.o")])
+    return lib
+
+
 if __name__ == "__main__":
     build(verbose=True)

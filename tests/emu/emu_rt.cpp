@@ -14,6 +14,8 @@
 namespace emu {
 
 thread_local Ctx g;
+int check_uniform_on = [] { const char* e = getenv("Y5M_EMU_CHECK_UNIFORM"); return e ? atoi(e) : 1; }();
+int defer_dma_on = [] { const char* e = getenv("Y5M_EMU_DEFER_DMA"); return e ? atoi(e) : 1; }();
 
 // ---- context switch (x86-64 SysV): callee-saved registers + stack pointer ---------------------------------------------
 extern "C" void emu_switch(void** save_sp, void* load_sp);
@@ -94,6 +96,44 @@ static void prepare(Lane& l) {
     l.sp = sp;
     l.state = RUNNABLE;
     l.op = 0;
+    l.nulog = 0;
+    l.ulog_overflow = false;
+    l.dma_head = l.dma_cnt = 0;
+}
+
+// The wave stands still (every live lane parked at a rendezvous or a barrier, the others done): compare what its lanes passed
+// through readfirstlane since the last stand-still. Entry e of a lane is the k-th execution of its source line in this interval;
+// on the GPU the lanes that execute that instruction together all receive ONE value (the first active lane's), so every lane that
+// logged (line, k) must have logged the same value.
+static void check_uniform(Wave& W, int w, Dim3 bid) {
+    struct Ref { const char* file; int line, k, lane; unsigned long long val; };
+    Ref refs[ULOG_MAX];
+    int nrefs = 0;
+    bool any = false;
+    for (int i = 0; i < W.n; ++i) any |= W.lanes[i]->nulog > 0;
+    if (!any) return;
+    for (int i = 0; i < W.n; ++i) {
+        Lane* l = W.lanes[i];
+        for (int e = 0; e < l->nulog; ++e) {
+            const UEntry& u = l->ulog[e];
+            int k = 0;
+            for (int f = 0; f < e; ++f) k += l->ulog[f].file == u.file && l->ulog[f].line == u.line;
+            int r = 0;
+            for (; r < nrefs; ++r)
+                if (refs[r].file == u.file && refs[r].line == u.line && refs[r].k == k) break;
+            if (r == nrefs) {
+                if (nrefs < ULOG_MAX) refs[nrefs++] = Ref{u.file, u.line, k, l->lane, u.val};
+                continue;
+            }
+            if (refs[r].val != u.val) {
+                fprintf(stderr, "emu: readfirstlane of a value that is NOT wave-uniform at %s:%d (execution %d since the last rendezvous), "
+                        "wave %d of block (%u,%u,%u): lane %d holds 0x%llx, lane %d holds 0x%llx -- the GPU would hand every lane the "
+                        "first active lane's value\n", u.file, u.line, k, w, bid.x, bid.y, bid.z, refs[r].lane, refs[r].val, l->lane, u.val);
+                abort();
+            }
+        }
+        l->nulog = 0;
+    }
 }
 
 static void run_block(Dim3 bid, Dim3 grid, Dim3 block, const void* kernarg) {
@@ -146,6 +186,7 @@ static void run_block(Dim3 bid, Dim3 grid, Dim3 block, const void* kernarg) {
                     progress = true;
                 }
             }
+            if (check_uniform_on) check_uniform(W, w, bid);      // (no lane of this wave is runnable here)
             int ncoll = 0, nlive = 0, nbar = 0, op = -1;
             bool same = true;
             for (int i = 0; i < W.n; ++i) {

@@ -195,7 +195,10 @@ static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_s_nop(n) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
-static inline void emu_waitcnt() { emu::wave_sync(); }       // stand-in of `s_waitcnt ...` (tests/emu/translate.py)
+// stand-ins of `s_waitcnt vmcnt(n)` / `s_waitcnt lgkmcnt(n)` (tests/emu/translate.py keeps the operand): the LDS-DMA loads of this
+// wave beyond the n newest land (emu_rt.h: dma_wait), then a wave-level rendezvous (lanes run one after the other)
+static inline void emu_waitcnt_vm(int n) { emu::dma_wait(n); emu::wave_sync(); }
+static inline void emu_waitcnt_lgkm(int) { emu::wave_sync(); }
 static inline unsigned long long emu_memtime() { return 0; }
 #define __builtin_readcyclecounter() 0ull
 
@@ -241,9 +244,28 @@ static inline int __all(int pred) {
     return 1;
 }
 // readfirstlane: its uses make a wave-uniform value scalar -> the calling lane's own value (no rendezvous, so it may sit in
-// divergent code exactly as on the GPU)
-template <typename T> static inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
-static inline int __builtin_amdgcn_readlane(int v, int l) { return emu_shfl_idx(v, l); }
+// divergent code exactly as on the GPU). The GPU would broadcast the FIRST ACTIVE lane's value: a kernel that passes a value
+// that is not uniform computes something else there than here, so every call is logged and the scheduler compares the lanes
+// (emu_rt.h: note_uniform / emu_rt.cpp: check_uniform; aborts with the source line).
+template <typename T> static inline T emu_readfirstlane(T v, const char* file, int line) {
+    emu::note_uniform(file, line, &v, sizeof(T));
+    return v;
+}
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane((v), __FILE__, __LINE__)
+// readlane: the lane index is a scalar operand on the GPU -- it must be the same on every lane (checked)
+static inline int __builtin_amdgcn_readlane(int v, int l) {
+    struct Op { int v, l; };
+    auto c = emu::coll_begin();
+    c.mine<Op>() = Op{v, l};
+    emu::coll_sync(9);
+    for (int i = 0; i < 64; ++i)
+        if (c.live(i) && c.of<Op>(i).l != l) {
+            fprintf(stderr, "emu: readlane with a lane index that is not wave-uniform (lane %d: %d, lane %d: %d)\n", c.lane, l, i, c.of<Op>(i).l);
+            abort();
+        }
+    l &= 63;
+    return c.live(l) ? c.of<Op>(l).v : v;
+}
 static inline int __builtin_amdgcn_sbfe(int v, int off, int width) {
     off &= 31; width &= 31;            // (s_bfe_i32: sign-extended bit field)
     if (width == 0) return 0;
@@ -303,7 +325,7 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(emu_rsrc r, unsign
 static inline void emu_buffer_load_lds16(emu_rsrc r, unsigned voff, unsigned soff, unsigned lds_addr) {
     const emu_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     unsigned char* lds = reinterpret_cast<unsigned char*>(((uintptr_t)emu::g.dyn_lds & ~(uintptr_t)0xffffffffu) | lds_addr);
-    memcpy(lds + 16 * emu::g.cur->lane, &v, 16);
+    emu::dma_issue(lds + 16 * emu::g.cur->lane, &v);          // lands at a covering s_waitcnt vmcnt(n), not before
 }
 
 // ---- matrix cores --------------------------------------------------------------------------------------------------------

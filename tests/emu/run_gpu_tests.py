@@ -1,5 +1,5 @@
 """Developer tool: run the test functions of a tests/test_gpu_*.py module on the CPU lane-level executor and print one line
-per parametrised case (status, seconds). Usage: python tests/emu/run_gpu_tests.py test_gpu_conv [name filter] [--max-s 30]
+per parametrised case (status, seconds). Usage: python tests/emu/run_gpu_tests.py test_gpu_conv [name filter] [--skip=regex] [--only=regex]
 TEST INFRASTRUCTURE (tests/test_emu_kernels.py holds the curated subset that runs in the -m "not gpu" suite)."""
 import importlib
 import itertools
@@ -45,10 +45,12 @@ def main():
     modname = sys.argv[1]
     filt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else ""
     import re
-    skip = None
+    skip = only = None
     for a in sys.argv[2:]:
         if a.startswith("--skip="):
             skip = re.compile(a[7:])
+        if a.startswith("--only="):
+            only = re.compile(a[7:])
     mod = importlib.import_module(modname)
     mod.DEV = "cpu"
     import numpy as np
@@ -61,7 +63,7 @@ def main():
     with emulated():
         for name in sorted(n for n in dir(mod) if n.startswith("test_") and filt in n):
             fn = getattr(mod, name)
-            if not callable(fn) or (skip is not None and skip.search(name)):
+            if not callable(fn) or (skip is not None and skip.search(name)) or (only is not None and not only.search(name)):
                 continue
             import inspect
             params = inspect.signature(fn).parameters

@@ -49,7 +49,7 @@ def _wgrad_name(B, Cin, H, W, Cout, k, s):
     return buf.value.decode()
 
 
-_DEFAULT_ENV = not any(k.startswith("Y5M_CONV") or k.startswith("Y5M_WGRAD") for k in os.environ)
+_DEFAULT_ENV = not any(k.startswith(("Y5M_CONV", "Y5M_WGRAD", "Y5M_R4")) for k in os.environ)
 
 CONV_DEFAULTS = [
     # B, Cin, H, W, Cout, k, s -> forward (raw + statistics), data gradient
@@ -68,8 +68,8 @@ WGRAD_DEFAULTS = [
     ((64, 384, 40, 40, 768, 3, 2), "wgrad_kernel<bf16,2,2,1,3,1,6,1>"),
     ((64, 96, 80, 80, 192, 3, 2), "wgrad_kernel<bf16,2,2,1,3,1,6,1>"),            # 192 x 96 block tile
     ((64, 96, 80, 80, 96, 3, 1), "wgrad_kernel<bf16,2,2,1,3,1,3,1>"),
-    ((64, 48, 320, 320, 96, 3, 2), "wgrad_rows_kernel<2,2,2>"),                   # 48 input channels: one kernel row per block
-    ((64, 48, 160, 160, 48, 3, 1), "wgrad_rows_kernel<1,4,1>"),
+    ((64, 48, 320, 320, 96, 3, 2), "wgrad_rows_kernel<2,2,2,0>"),                   # 48 input channels: one kernel row per block
+    ((64, 48, 160, 160, 48, 3, 1), "wgrad_rows_kernel<1,4,1,0>"),
     ((64, 16, 320, 320, 48, 3, 1), "wgrad_kernel<bf16,1,1,4,9,9,3,0>"),           # stem: all nine taps in one block
     ((64, 384, 20, 20, 384, 1, 1), "wgrad_kernel<bf16,2,2,1,3,1,6,1>"),           
 ]

@@ -1,0 +1,105 @@
+"""CPU: the executor's two hazard models (tests/emu/include/emu_rt.h, round 5) catch what they are there for.
+
+Each test builds a DELIBERATELY BROKEN variant of a real kernel source (a textual edit, compiled into build/emu/liby5m_emu_<tag>.so;
+the product source is untouched), runs the op-level GPU test of that kernel on it in a child process and expects the executor to
+object -- and the unbroken library to pass the same case. TEST INFRASTRUCTURE."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+
+CHILD = r'''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from emu.harness import emulated
+import test_gpu_conv as T
+T.DEV = "cpu"
+with emulated():
+    %s
+print("CHILD-PASSED")
+'''
+
+
+def _child(body, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    e.setdefault("Y5M_EMU_THREADS", "4")
+    return subprocess.run([sys.executable, "-c", CHILD % (ROOT, HERE, body)], env=e, capture_output=True, text=True, timeout=900)
+
+
+def _variant(tag, edits):
+    from emu import build as B
+    if not os.path.exists(B.CXX):
+        pytest.skip("host clang of the ROCm image not present")
+    return B.build_variant(tag, edits)
+
+
+def test_readfirstlane_of_a_nonuniform_value_is_caught():
+    """wgrad_rows_kernel's round-4 form keeps the run state in scalar registers: (row, run) of the first chunk go through
+    readfirstlane. A variant that passes a LANE-DEPENDENT value there computes garbage on the GPU (every lane gets lane 0's
+    value) but the right answer on a plain per-lane executor -- the uniformity check must abort on it."""
+    lib = _variant("rfl", {"y5m_conv_wgrad.hip": lambda s: s.replace(
+        "j = __builtin_amdgcn_readfirstlane(j);", "j = __builtin_amdgcn_readfirstlane(j + (lane >> 5)) - (lane >> 5);")})
+    body = "T.test_conv_wgrad_rows_kernel((2, 48, 24, 50, 96, 3, 2, 1))"
+    bad = _child(body, Y5M_EMU_LIB=lib, Y5M_R4_KERNELS=1)
+    assert bad.returncode != 0 and "NOT wave-uniform" in bad.stderr and "y5m_conv_wgrad.hip" in bad.stderr, (bad.returncode, bad.stderr[-800:])
+    # the same broken library with the check off: the per-lane arithmetic is "right", the test passes -- which is the blind spot
+    blind = _child(body, Y5M_EMU_LIB=lib, Y5M_R4_KERNELS=1, Y5M_EMU_CHECK_UNIFORM=0)
+    assert blind.returncode == 0 and "CHILD-PASSED" in blind.stdout, blind.stderr[-800:]
+    good = _child(body, Y5M_R4_KERNELS=1)
+    assert good.returncode == 0 and "CHILD-PASSED" in good.stdout, good.stderr[-800:]
+
+
+def test_missing_wait_behind_lds_dma_reads_stale_lds():
+    """conv_halo_kernel's prologue stages the first patch and two weight slices with LDS-DMA loads and waits for them with
+    `s_waitcnt vmcnt(0)` in front of the barrier. Without that wait the first unit's fragments are read before the data has landed:
+    with deferred completion the executor's LDS still holds what was there before, and the forward result is wrong."""
+    def drop_wait(s):
+        i = s.index("// ---- prologue: first patch, weights of units 0 and 1")
+        j = s.index('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', i)
+        return s[:j] + s[j + len('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");'):]
+    lib = _variant("nowait", {"y5m_conv_halo.hip": drop_wait})
+    body = "T.test_halo_forward_stats_and_epilogue((2, 192, 20, 20, 192))"
+    bad = _child(body, Y5M_EMU_LIB=lib)
+    assert bad.returncode != 0 and "AssertionError" in bad.stderr, (bad.returncode, bad.stderr[-800:])
+    # loads that land at once (the executor before round 5) cannot see it
+    blind = _child(body, Y5M_EMU_LIB=lib, Y5M_EMU_DEFER_DMA=0)
+    assert blind.returncode == 0 and "CHILD-PASSED" in blind.stdout, blind.stderr[-800:]
+    good = _child(body)
+    assert good.returncode == 0 and "CHILD-PASSED" in good.stdout, good.stderr[-800:]
+
+
+def test_too_weak_wait_behind_lds_dma_is_caught():
+    """the same prologue with `vmcnt(2)`: the two newest loads of every wave may still be in flight at the barrier"""
+    def weaken(s):
+        i = s.index("// ---- prologue: first patch, weights of units 0 and 1")
+        j = s.index('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', i)
+        return s[:j] + 'asm volatile("s_waitcnt vmcnt(2)" ::: "memory");' + s[j + len('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");'):]
+    lib = _variant("weakwait", {"y5m_conv_halo.hip": weaken})
+    bad = _child("T.test_halo_forward_stats_and_epilogue((2, 192, 20, 20, 192))", Y5M_EMU_LIB=lib)
+    assert bad.returncode != 0 and "AssertionError" in bad.stderr, (bad.returncode, bad.stderr[-800:])
+
+
+def test_round4_kernel_forms_green_on_the_executor():
+    """the five round-4 kernel rewrites sit behind Y5M_R4_KERNELS (default 0 = the round-3 forms that ran on hardware; csrc/
+    y5m_common.h). The regular executor suite runs the default; this runs the op-level cases of those five kernels with all five
+    round-4 forms selected (a child: the mask is read once per process), under the uniformity check and deferred LDS-DMA."""
+    e = dict(os.environ, Y5M_R4_KERNELS="31", Y5M_EMU_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "run_gpu_tests.py"), "test_gpu_conv",
+                        "--only=wgrad_rows|bwd_pw_fused|bwd_stem_fused|bn_act_and_backward"], env=e, capture_output=True, text=True, timeout=1500)
+    lines = [l for l in r.stdout.splitlines() if " test_" in l]
+    assert r.returncode == 0 and len(lines) >= 40, (r.returncode, r.stderr[-800:])
+    bad = [l for l in lines if not l.endswith(" ok")]
+    assert not bad, bad[:3]
+    # the names the dispatch reports carry the form: a case that silently ran the round-3 form would prove nothing
+    c = _child('from yolov5m_amd import ops\n    T.test_conv_wgrad_rows_kernel((1, 48, 11, 13, 96, 3, 2, 1))\n    assert ops.LAST_WGRAD_KERNEL.endswith(",1>"), ops.LAST_WGRAD_KERNEL',
+               Y5M_R4_KERNELS=31)
+    assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-800:]
+    c = _child('from yolov5m_amd import ops\n    T.test_conv_wgrad_rows_kernel((1, 48, 11, 13, 96, 3, 2, 1))\n    assert ops.LAST_WGRAD_KERNEL.endswith(",0>"), ops.LAST_WGRAD_KERNEL')
+    assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-800:]

@@ -406,7 +406,7 @@ def test_bf16_per_layer_backward_full_size_default_dispatch():
     print("per-layer bf16 backward at B=64 @ 640: worst", {k: f"{v:.2e}" for k, v in worst.items()}, "dx-checked layers", checked_dx,
           "kernels", sorted(names))
     assert kinds.count("bwd_pw") >= 10 and kinds.count("bwd_stem") == 1, (kinds.count("bwd_pw"), kinds.count("bwd_stem"))
-    assert any(n.startswith("wgrad_rows_kernel<2,2,2>") for n in names) and any(n.startswith("wgrad_rows_kernel<1,4,1>") for n in names), names
+    assert any(n.startswith("wgrad_rows_kernel<2,2,2,") for n in names) and any(n.startswith("wgrad_rows_kernel<1,4,1,") for n in names), names
     assert any(n.startswith("conv_halo_kernel<6,3>") for n in names) and any(n.startswith("conv_igemm_multi") or "igemm" in n for n in names), names
     assert checked_dx >= 8
 

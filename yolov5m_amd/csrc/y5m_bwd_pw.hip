@@ -82,7 +82,9 @@ extern "C" int y5m_debug_bp_timing(unsigned long long* host) {
 #define BP_STAMP(i)
 #endif
 
-template <int C, bool OLD>
+// R4 (Y5M_R4_KERNELS bit 3, y5m_common.h): the next tile's pieces re-requested unconditionally and rows behind M masked with a bit
+// mask (round 4, not yet measured on hardware); false = the round-3 form (branch around the re-request, select), hardware-verified.
+template <int C, bool OLD, bool R4>
 __global__ __launch_bounds__(BP_THREADS, 2) void bwd_pw_kernel(const BwdPwParams P, const int ntiles) {
     using G = BpCfg<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(BP_THREADS, 2) void bwd_pw_kernel(const BwdPwParams
         // ---- phase A: dy from (dz, y), dy and x into the LDS tiles ---------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const unsigned inm = (long long)tile * G::TP + pp[i] < P.M ? 0xffffffffu : 0u;      // all ones for a row in front of M
+            const bool in = (long long)tile * G::TP + pp[i] < P.M;
+            const unsigned inm = in ? 0xffffffffu : 0u;                                         // all ones for a row in front of M
             const int c0 = pc[i] * 8;
             float sc[8], sh[8], kb[8], mu[8], kd[8];
 #pragma unroll
@@ -221,14 +224,18 @@ __global__ __launch_bounds__(BP_THREADS, 2) void bwd_pw_kernel(const BwdPwParams
             }
             u32x4 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) & inm;   // rows behind M contribute nothing
+            for (int q = 0; q < 4; ++q) {                                                       // rows behind M contribute nothing
+                if constexpr (R4) o[q] = f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) & inm;
+                else o[q] = in ? f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) : 0u;
+            }
             *reinterpret_cast<u32x4*>(ytile + lofs_y[i]) = o;
             *reinterpret_cast<u32x4*>(xtile + lofs_x[i]) = rx[i];
             // this piece's registers are free: the next tile's piece is requested right away and flies under the rest of
-            // phase A and phases C and B. UNCONDITIONALLY (behind the last tile the clamped row M - 1 is read once more and never
+            // phase A and phases C and B. R4: UNCONDITIONALLY (behind the last tile the clamped row M - 1 is read once more and never
             // used): with a branch around the request the compiler cannot count the loads across it and waits with vmcnt(0) for the
             // last group of a tile -- i.e. also for the two groups it has just re-requested (round 4, tools/isa_audit.py)
-            issue_piece(tile + (int)gridDim.x, i);
+            if constexpr (R4) issue_piece(tile + (int)gridDim.x, i);
+            else { if (tile + (int)gridDim.x < ntiles) issue_piece(tile + gridDim.x, i); }
         }
         __syncthreads();
 
@@ -420,15 +427,16 @@ static int launch_bp(const BwdPwParams& P, hipStream_t st) {
     int grid = y5m_persistent_cus();          // one 8-wave workgroup per CU (the 48- / 96-channel forms would need <= 128 VGPRs for two: they spill)
     if (grid > ntiles) grid = ntiles;
     const bool old = P.dx && (P.accumulate || P.res);
-    auto k0 = bwd_pw_kernel<C, false>;
-    auto k1 = bwd_pw_kernel<C, true>;
+    const bool r4 = (y5m_r4_forms() & Y5M_R4_BWD_PW) != 0;
+    auto k0 = r4 ? bwd_pw_kernel<C, false, true> : bwd_pw_kernel<C, false, false>;
+    auto k1 = r4 ? bwd_pw_kernel<C, true, true> : bwd_pw_kernel<C, true, false>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr = true;
     }
-    Y5M_NAME_ONLY(Y5M_OK, "bwd_pw_kernel<%d,%d>", C, (int)old);
+    Y5M_NAME_ONLY(Y5M_OK, "bwd_pw_kernel<%d,%d,%d>", C, (int)old, (int)r4);
     if (old) hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(BP_THREADS), G::LDS, st, P, ntiles);
     else hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(BP_THREADS), G::LDS, st, P, ntiles);
     Y5M_CHECK_LAUNCH("bwd_pw_kernel");

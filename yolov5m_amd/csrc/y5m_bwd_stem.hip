@@ -38,6 +38,9 @@ typedef y5m_bwd_stem_args BwdStemParams;
 #define BS_YP (BS_RUNS * 32 * 6)           // 16-byte pieces of dz (and of y) per chunk: 1536 = 3 per thread
 #define BS_XP (BS_RUNS * 3 * BS_NPX * 2)   // of x: 1632 -> 4 per thread, the last partly empty
 
+// R4 (Y5M_R4_KERNELS bit 2, y5m_common.h): the streaming loop as straight-line code (round 4, not yet measured on hardware);
+// false = the round-3 form (branches around the re-requests and the X stores), hardware-verified.
+template <bool R4>
 __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemParams P, const int spr, const int nruns, const int nchunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ytile = smem;
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
         xpx[i] = rem2 >> 1;
         xhalf[i] = rem2 & 1;
         // (a piece behind the tile stores into the dummy region behind the coefficients: the store is unconditional)
-        xofs[i] = q < BS_XP ? (xrun[i] * 3 + xty[i]) * BS_XG + xpx[i] * 32 + xhalf[i] * 16 : BS_XB + BS_COEF + (lane & 3) * 16;
+        if constexpr (R4) xofs[i] = q < BS_XP ? (xrun[i] * 3 + xty[i]) * BS_XG + xpx[i] * 32 + xhalf[i] * 16 : BS_XB + BS_COEF + (lane & 3) * 16;
+        else xofs[i] = ((q < BS_XP ? xrun[i] : 0) * 3 + xty[i]) * BS_XG + xpx[i] * 32 + xhalf[i] * 16;
     }
     const float rcpS = 1.0f / (float)spr, rcpH = 1.0f / (float)P.H;
     const unsigned ldzb = (unsigned)(P.lddz * 2), ldyb = (unsigned)(P.ldy * 2), ldxb = (unsigned)(P.ldx * 2);
@@ -145,12 +149,17 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
     };
 
     int chunk = blockIdx.x;
-    {
+    if constexpr (R4) {
         const bool first = chunk < nchunks;
 #pragma unroll
         for (int i = 0; i < 3; ++i) issue_zy(chunk, first, i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_x(chunk, first, i);
+    } else if (chunk < nchunks) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) issue_zy(chunk, true, i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_x(chunk, true, i);
     }
     __syncthreads();                                      // coefficients are in place
     for (; chunk < nchunks; chunk += gridDim.x) {
@@ -171,6 +180,7 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { sc[4 * h + k] = a0[k]; sh[4 * h + k] = a1[k]; kb[4 * h + k] = a2[k]; mu[4 * h + k] = a3[k]; kd[4 * h + k] = a4[k]; }
             }
+            const bool in = (okm >> i) & 1u;
             const unsigned inm = 0u - ((okm >> i) & 1u);   // all ones for a real pixel
             float dy[8];
 #pragma unroll
@@ -185,14 +195,23 @@ __global__ __launch_bounds__(BS_THREADS, 1) void bwd_stem_kernel(const BwdStemPa
             }
             u32x4 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) & inm;     // masked pixels contribute nothing
+            for (int q = 0; q < 4; ++q) {                                                         // masked pixels contribute nothing
+                if constexpr (R4) o[q] = f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) & inm;
+                else o[q] = in ? f32x2_to_bf16x2(dy[2 * q], dy[2 * q + 1]) : 0u;
+            }
             *reinterpret_cast<u32x4*>(ytile + zofs[i]) = o;
-            issue_zy(next, more, i);
+            if constexpr (R4) issue_zy(next, more, i);
+            else { if (next < nchunks) issue_zy(next, true, i); }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(xtile + xofs[i]) = rx[i];
-            issue_x(next, more, i);
+            if constexpr (R4) {
+                *reinterpret_cast<u32x4*>(xtile + xofs[i]) = rx[i];
+                issue_x(next, more, i);
+            } else {
+                if (xrun[i] >= 0) *reinterpret_cast<u32x4*>(xtile + xofs[i]) = rx[i];
+                if (next < nchunks) issue_x(next, true, i);
+            }
         }
         __syncthreads();
         // ---- phase C: this wave's run: 9 taps x 3 dY fragments, K = the run's 32 pixels ------------------------------------------
@@ -267,13 +286,16 @@ extern "C" int y5m_bwd_stem(const y5m_bwd_stem_args* args, void* stream) {
     const int nchunks = (nruns + BS_RUNS - 1) / BS_RUNS;
     int grid = y5m_persistent_cus();
     if (grid > nchunks) grid = nchunks;
+    const bool r4 = (y5m_r4_forms() & Y5M_R4_BWD_STEM) != 0;
+    auto kern = r4 ? bwd_stem_kernel<true> : bwd_stem_kernel<false>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)bwd_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
+        (void)hipFuncSetAttribute((const void*)bwd_stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
+        (void)hipFuncSetAttribute((const void*)bwd_stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
         attr = true;
     }
-    Y5M_NAME_ONLY(Y5M_OK, "bwd_stem_kernel");
-    hipLaunchKernelGGL(bwd_stem_kernel, dim3((unsigned)grid), dim3(BS_THREADS), BS_LDS, y5m_stream(stream), P, spr, nruns, nchunks);
+    Y5M_NAME_ONLY(Y5M_OK, "bwd_stem_kernel<%d>", (int)r4);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS_THREADS), BS_LDS, y5m_stream(stream), P, spr, nruns, nchunks);
     Y5M_CHECK_LAUNCH("bwd_stem_kernel");
     return Y5M_OK;
 }

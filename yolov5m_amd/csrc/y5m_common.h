@@ -55,6 +55,23 @@ static inline int y5m_persistent_cus() {
     return cus;
 }
 
+// Round-4 kernel forms. Five hot-path kernels were rewritten in round 4 from a static audit of their generated code
+// (tools/isa_audit.py) while no GPU was reachable; their round-3 forms passed the GPU suite on hardware. Both forms are compiled
+// (a template parameter per kernel); Y5M_R4_KERNELS is the bit mask of the round-4 forms to use. The default is 0 -- only code
+// that has run on a gfx950 is on the default path -- until tools/ab_r4_kernels.sh has decided each bit on hardware.
+enum {
+    Y5M_R4_WGRAD_ROWS = 1,      // wgrad_rows_kernel: run state on the scalar unit
+    Y5M_R4_BN_ACT = 2,          // bn_act_kernel: residual rows loaded raw
+    Y5M_R4_BWD_STEM = 4,        // bwd_stem_kernel: straight-line streaming loop
+    Y5M_R4_BWD_PW = 8,          // bwd_pw_kernel: unconditional re-requests
+    Y5M_R4_BN_BWD_REDUCE = 16,  // bn_bwd_reduce_kernel: raw loads behind one scheduling barrier
+};
+static inline int y5m_r4_forms() {
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("Y5M_R4_KERNELS"); mask = e ? (atoi(e) & 31) : 0; }
+    return mask;
+}
+
 int y5m_fill32(void* p, uint32_t v, size_t n_words, hipStream_t st);      // y5m_core.hip: 32-bit fill as a kernel launch
 
 static inline hipStream_t y5m_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

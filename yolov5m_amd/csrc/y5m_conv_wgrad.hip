@@ -427,7 +427,9 @@ struct WrCfg {
     static constexpr int LDS = (YB + XB) > RED ? (YB + XB) : RED;
 };
 
-template <int WN, int WK, int S>
+// R4: the round-4 form of the address arithmetic (scalar run state; made from the static ISA audit and not yet measured on
+// hardware: selected by Y5M_R4_KERNELS bit 0, y5m_common.h); false = the round-3 form (per-piece divisions), hardware-verified.
+template <int WN, int WK, int S, bool R4>
 __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, const int spr, const int nruns) {
     using C = WrCfg<WN, WK, S>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -495,7 +497,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
         sj = 0;
     };
     const unsigned ystep = 32u * ldyb, xstep = (unsigned)(32 * P.sx) * ldxb;
-    {
+    su0 = sj = soy = sb = sylim = sxix = 0; sybase = sxbase = 0u;
+    if constexpr (R4) {
         su0 = __builtin_amdgcn_readfirstlane(ch_lo * WK);
         int row, j, b, oy;
         fast_divmod(su0, spr, rcpS, row, j);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
         sj = j; sybase += (unsigned)j * ystep; sxbase += (unsigned)j * xstep; sylim -= 32 * j;
         if (sxix != 0x40000000) sxix += 32 * P.sx * j;
     }
-    auto load_next = [&]() __attribute__((always_inline)) {
+    auto load_next_r4 = [&]() __attribute__((always_inline)) {
         unsigned ybase[WK], xbase[WK];
         int ylim[WK], xix0[WK];
 #pragma unroll
@@ -549,6 +552,33 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
             const bool ok = xks[i] >= 0 && (unsigned)(ix0 + xpx[i]) < (unsigned)P.Win;
             rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? base + xcst[i] : OOB, 0, 0);
         }
+    };
+    // round-3 form: (run, row, image) of every 16-byte piece recomputed per lane with two divisions
+    auto load_chunk_r3 = [&](int chk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::NLDY; ++i) {
+            const int u = chk * WK + yks[i];
+            int row, j;
+            fast_divmod(u, spr, rcpS, row, j);                        // row = b * Hg + oy
+            const int ox = 32 * j + ypx[i];
+            const bool ok = yks[i] >= 0 && u < nruns && ox < P.Wg;
+            const unsigned m = (unsigned)(row * P.Wg + ox);
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, ok ? m * ldyb + (unsigned)(ycc[i] * 16) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::NLDX; ++i) {
+            const int u = chk * WK + xks[i];
+            int row, j, b, oy;
+            fast_divmod(u, spr, rcpS, row, j);
+            fast_divmod(row, P.Hg, rcpH, b, oy);
+            const int iy = oy * P.sy + dh, ix = 32 * j * P.sx + P.dw0 + xpx[i];
+            const bool ok = xks[i] >= 0 && u < nruns && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            const unsigned pix = __umul24((unsigned)(b * P.Hin + iy), (unsigned)P.Win) + (unsigned)ix;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? __umul24(pix, ldxb) + (unsigned)(xcc[i] * 16) : OOB, 0, 0);
+        }
+    };
+    auto load_chunk = [&](int chk) __attribute__((always_inline)) {   // chunk chk (R4: chunks are taken in order, chk is implied)
+        if constexpr (R4) load_next_r4(); else load_chunk_r3(chk);
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
         unsigned char* Ys = smem;
@@ -599,12 +629,12 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
     };
 
     if (ch_lo < ch_hi) {
-        load_next();
+        load_chunk(ch_lo);
         store_chunk();
         __syncthreads();
         for (int chk = ch_lo; chk < ch_hi; ++chk) {
             const bool more = chk + 1 < ch_hi;
-            if (more) load_next();
+            if (more) load_chunk(chk + 1);
             compute();
             __syncthreads();
             if (more) store_chunk();
@@ -648,8 +678,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const WgradParams P, co
     }
 }
 
-template <int WN, int WK, int S>
-static int launch_wgrad_rows(WgradParams& P, hipStream_t st) {
+template <int WN, int WK, int S, bool R4>
+static int launch_wgrad_rows_form(WgradParams& P, hipStream_t st) {
     using C = WrCfg<WN, WK, S>;
     const int spr = (P.Wg + 31) / 32;                    // runs per output row
     const int nruns = P.B * P.Hg * spr;
@@ -663,16 +693,22 @@ static int launch_wgrad_rows(WgradParams& P, hipStream_t st) {
         P.ksplit = ks < 1 ? 1 : ks;
     }
     P.tiles_n = P.tiles_c = 1;
-    auto kern = wgrad_rows_kernel<WN, WK, S>;
+    auto kern = wgrad_rows_kernel<WN, WK, S, R4>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         attr = true;
     }
-    Y5M_NAME_ONLY(Y5M_OK, "wgrad_rows_kernel<%d,%d,%d>", WN, WK, S);
+    Y5M_NAME_ONLY(Y5M_OK, "wgrad_rows_kernel<%d,%d,%d,%d>", WN, WK, S, (int)R4);
     hipLaunchKernelGGL(kern, dim3((unsigned)(3 * P.ksplit)), dim3(256), C::LDS, st, P, spr, nruns);
     Y5M_CHECK_LAUNCH("wgrad_rows_kernel");
     return Y5M_OK;
+}
+
+template <int WN, int WK, int S>
+static int launch_wgrad_rows(WgradParams& P, hipStream_t st) {
+    return (y5m_r4_forms() & Y5M_R4_WGRAD_ROWS) ? launch_wgrad_rows_form<WN, WK, S, true>(P, st)
+                                                : launch_wgrad_rows_form<WN, WK, S, false>(P, st);
 }
 
 // 1 when the launch qualifies for wgrad_rows_kernel

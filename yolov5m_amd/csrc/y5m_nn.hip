@@ -500,7 +500,9 @@ struct BnFusedFwd {
 };
 
 // z = act(y*scale + shift) (+ res)
-template <typename T, bool FUSED>
+// R4 (Y5M_R4_KERNELS bit 1, y5m_common.h): residual rows kept raw and unpacked where they are added (round 4, not yet measured
+// on hardware); false = the round-3 form (residual rows unpacked behind their loads), hardware-verified.
+template <typename T, bool FUSED, bool R4>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const T* __restrict__ res, int ldres,
                                                     T* __restrict__ out, int ldout, int64_t M, int CG, int RP, int act,
@@ -512,7 +514,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
     const bool active = rl < RP;
     float sc[8], sh[8];
     float v[4][8];
-    Raw8<T> r[4];                                           // residual rows, unpacked where they are added (finish4)
+    Raw8<T> r[4];                                           // R4: residual rows, unpacked where they are added (finish4)
+    float r3[R4 ? 1 : 4][8];                                // round-3 form: residual rows as floats
+    auto load_res = [&](int u) __attribute__((always_inline)) {
+        if constexpr (R4) raw_load8(res + (m + u * stride) * ldres + c, r[u]);
+        else load8<T>(res + (m + u * stride) * ldres + c, r3[u]);
+    };
     // FUSED: the first four rows are requested BEFORE the coefficient prologue, so that its round trip to the accumulator
     // rows and its f64 arithmetic run under their HBM latency (without this every workgroup starts with ~3 us of nothing in
     // flight: +4 us per launch with the ~4 rounds of workgroups a CU runs)
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, v[u]);
-            if (res) raw_load8(res + (m + u * stride) * ldres + c, r[u]);
+            if (res) load_res(u);
         }
     }
     if constexpr (FUSED) {
@@ -565,12 +572,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (res) raw_unpack8(r[u], rr);
+            if constexpr (R4) { if (res) raw_unpack8(r[u], rr); }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 v[u][k] = v[u][k] * sc[k] + sh[k];
                 if (act == Y5M_ACT_SILU) v[u][k] = silu_f(v[u][k]);
-                if (res) v[u][k] += rr[k];
+                if constexpr (R4) { if (res) v[u][k] += rr[k]; }
+                else { if (res) v[u][k] += r3[u][k]; }
             }
             store8<T>(out + (m + u * stride) * ldout + c, v[u]);
         }
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             LOAD8_STREAM<T>(y + (m + u * stride) * ldy + c, v[u]);
-            if (res) raw_load8(res + (m + u * stride) * ldres + c, r[u]);
+            if (res) load_res(u);
         }
         finish4();
     }
@@ -604,9 +612,11 @@ extern "C" int y5m_bn_act(const void* y, int ldy, const float* scale, const floa
     Y5M_REQUIRE(!res || (ldres % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0 && (dtype != Y5M_BF16 || ldres % 8 == 0)),
                 "res: 16-byte aligned rows (the residual is read in 16-byte pieces)");
     const EwGeom g = ew_geom(M, C / 8, 4096);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
-                                         (const T*)y, ldy, scale, shift, (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act,
-                                         BnFusedFwd{});)
+    DISPATCH_T(dtype, {
+        auto kern = (y5m_r4_forms() & Y5M_R4_BN_ACT) ? bn_act_kernel<T, false, true> : bn_act_kernel<T, false, false>;
+        hipLaunchKernelGGL(kern, dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream), (const T*)y, ldy, scale, shift,
+                           (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act, BnFusedFwd{});
+    })
     Y5M_CHECK_LAUNCH("bn_act_kernel");
     return Y5M_OK;
 }
@@ -640,9 +650,11 @@ extern "C" int y5m_bn_act_fused(const void* y, int ldy, const double* acc, int l
     const EwGeom g = ew_geom(M, C / 8, BNF_EW_GX);
     const BnFusedFwd F{acc, ldacc, (double)count, gamma, beta, running_mean, running_var, momentum, eps,
                        scale, shift, mean_out, invstd_out, update_running};
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream),
-                                         (const T*)y, ldy, (const float*)nullptr, (const float*)nullptr, (const T*)res, ldres,
-                                         (T*)out, ldout, M, g.CG, g.RP, act, F);)
+    DISPATCH_T(dtype, {
+        auto kern = (y5m_r4_forms() & Y5M_R4_BN_ACT) ? bn_act_kernel<T, true, true> : bn_act_kernel<T, true, false>;
+        hipLaunchKernelGGL(kern, dim3(g.gx, (unsigned)g.groups), dim3(256), 0, y5m_stream(stream), (const T*)y, ldy,
+                           (const float*)nullptr, (const float*)nullptr, (const T*)res, ldres, (T*)out, ldout, M, g.CG, g.RP, act, F);
+    })
     Y5M_CHECK_LAUNCH("bn_act_kernel");
     return Y5M_OK;
 }
@@ -664,12 +676,16 @@ extern "C" int y5m_bn_act_fused(const void* y, int ldy, const double* acc, int l
 #endif
 // accum != NULL: the block partials are ADDED into the accumulator rows accum[BNF_SLOTS][2][C] (y5m_bnfuse.h) instead of
 // being stored as partial rows
-template <typename T, bool SILU>
+// FORM (Y5M_R4_KERNELS bit 4, y5m_common.h): 0 = the round-3 form, hardware-verified (the activation a run-time argument, rows
+// unpacked behind their loads); 1 / 2 = the round-4 form without / with SiLU (compile-time activation, the eight loads of four
+// rows raw behind one scheduling barrier; not yet measured on hardware).
+template <typename T, int FORM>
 __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y,
                                                            int ldy, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
-                                                           int64_t M, int C, int CG, int RP, float* __restrict__ part,
+                                                           int64_t M, int C, int CG, int RP, int act, float* __restrict__ part,
                                                            double* __restrict__ accum) {
+    const bool SILU = FORM == 0 ? act == Y5M_ACT_SILU : FORM == 2;
     __shared__ float sm[2][BNR_THREADS][9];    // [which][thread][k] (+1: the 8-float rows land on distinct banks)
     const int cl = threadIdx.x % CG, rl = threadIdx.x / CG;
     const bool active = rl < RP;
@@ -684,6 +700,24 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_bwd_reduce_kernel(const T* __r
         load8<float>(mean + c, mu);
         const int64_t stride = (int64_t)gridDim.x * RP;
         int64_t m = (int64_t)blockIdx.x * RP + rl;
+        if constexpr (FORM == 0) {
+            for (; m + 3 * stride < M; m += 4 * stride) {
+                float g[4][8], yv[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    load8<T>(dz + (m + u * stride) * lddz + c, g[u]);
+                    load8<T>(y + (m + u * stride) * ldy + c, yv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float dt = act == Y5M_ACT_SILU ? g[u][k] * silu_grad(yv[u][k] * sc[k] + sh[k]) : g[u][k];
+                        s1[k] += dt;
+                        s2[k] += dt * (yv[u][k] - mu[k]);
+                    }
+            }
+        } else
         for (; m + 3 * stride < M; m += 4 * stride) {
             // the eight 16-byte loads of four rows are issued together and kept RAW (32 registers instead of 64 unpacked floats:
             // four waves per SIMD); a row is unpacked where it is consumed. SILU is a template parameter: the per-element test of
@@ -862,9 +896,10 @@ extern "C" int y5m_bn_bwd(const void* dz, int lddz, const void* y, int ldy, cons
     hipStream_t st = y5m_stream(stream);
     const EwGeom gr = ew_geom(M, C / 8, BNR_MAX_GX, BNR_THREADS);   // (swept 256..2048 in the full step: 512 is best)
     DISPATCH_T(dtype, {
-        auto kern = act == Y5M_ACT_SILU ? bn_bwd_reduce_kernel<T, true> : bn_bwd_reduce_kernel<T, false>;
+        auto kern = !(y5m_r4_forms() & Y5M_R4_BN_BWD_REDUCE) ? bn_bwd_reduce_kernel<T, 0>
+                    : act == Y5M_ACT_SILU ? bn_bwd_reduce_kernel<T, 2> : bn_bwd_reduce_kernel<T, 1>;
         hipLaunchKernelGGL(kern, dim3(gr.gx, (unsigned)gr.groups), dim3(BNR_THREADS), 0, st, (const T*)dz, lddz, (const T*)y, ldy,
-                           scale, shift, mean, M, C, gr.CG, gr.RP, part, (double*)nullptr);
+                           scale, shift, mean, M, C, gr.CG, gr.RP, act, part, (double*)nullptr);
     })
     Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     BnFinArgs F{};
@@ -895,9 +930,10 @@ extern "C" int y5m_bn_bwd_fused_phase(const void* dz, int lddz, const void* y, i
         if (rgx < 0) { const char* e = getenv("Y5M_BNR_GX"); rgx = e ? atoi(e) : BNR_MAX_GX; }
         const EwGeom grr = ew_geom(M, C / 8, rgx, BNR_THREADS);
         DISPATCH_T(dtype, {
-            auto kern = act == Y5M_ACT_SILU ? bn_bwd_reduce_kernel<T, true> : bn_bwd_reduce_kernel<T, false>;
+            auto kern = !(y5m_r4_forms() & Y5M_R4_BN_BWD_REDUCE) ? bn_bwd_reduce_kernel<T, 0>
+                        : act == Y5M_ACT_SILU ? bn_bwd_reduce_kernel<T, 2> : bn_bwd_reduce_kernel<T, 1>;
             hipLaunchKernelGGL(kern, dim3(grr.gx, (unsigned)grr.groups), dim3(BNR_THREADS), 0, st, (const T*)dz, lddz, (const T*)y,
-                               ldy, scale, shift, mean, M, C, grr.CG, grr.RP, (float*)nullptr, acc);
+                               ldy, scale, shift, mean, M, C, grr.CG, grr.RP, act, (float*)nullptr, acc);
         })
         Y5M_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     }

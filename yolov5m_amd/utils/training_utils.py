@@ -562,7 +562,8 @@ class NativeTrainStep:
                     kern.append((buf.value.decode(), ms, 2.0 * d[0].M * d[0].N * d[0].K))
             elif kind == "bwd_pw":
                 a = item[0].bp          # fused pointwise backward: data gradient + weight gradient flops; HBM-bound (bench.py by_class)
-                kern.append((f"bwd_pw_kernel<{a.C},{int(bool(a.accumulate or a.res))}>", ms, 4.0 * a.M * a.N * a.C,
+                r4 = (int(os.environ.get("Y5M_R4_KERNELS", "0") or 0) >> 3) & 1       # (the form launch_bp picks: csrc/y5m_common.h)
+                kern.append((f"bwd_pw_kernel<{a.C},{int(bool(a.accumulate or a.res))},{r4}>", ms, 4.0 * a.M * a.N * a.C,
                              float(a.M) * (2 * a.N + (3 if (a.accumulate or a.res) else 2) * a.C) * 2))     # + algorithmic bytes
             elif kind == "wgrad" and getattr(item[0], "wa", None) is not None:
                 wa = item[0].wa
