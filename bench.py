@@ -111,7 +111,7 @@ def first_loss_check(first_loss, B, S, rank):
     return out
 
 
-def forward_leg(model, dev, B=32, size=640, iters=10):
+def forward_leg(model, dev, B=32, size=640, iters=10, warm=3):
     """configs[1]: forward only, batch 32 @ 640x640, bf16: eval mode (BatchNorm folded into the conv epilogues) and
     train mode (batch statistics), images/s each (inputs resident in HBM)."""
     from yolov5m_amd.utils.synth import synth_images
@@ -120,7 +120,7 @@ def forward_leg(model, dev, B=32, size=640, iters=10):
     for mode in ("eval", "train"):
         model.train(mode == "train")
         with torch.no_grad():
-            for _ in range(3):
+            for _ in range(warm):
                 model(x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -130,10 +130,11 @@ def forward_leg(model, dev, B=32, size=640, iters=10):
         dt = (time.perf_counter() - t0) / iters
         out[mode] = {"images_per_sec": round(B / dt, 1), "ms": round(dt * 1e3, 3)}
     model.train(True)
-    return {"workload": f"forward only, batch {B} @ {size}x{size}, bf16 (BASELINE.json configs[1])", "unit": "images/s", **out}
+    tag = " (BASELINE.json configs[1])" if (B, size) == (32, 640) else ""
+    return {"workload": f"forward only, batch {B} @ {size}x{size}, bf16{tag}", "unit": "images/s", **out}
 
 
-def detect_leg(dev, model=None, B=128, size=1280, iters=5):
+def detect_leg(dev, model=None, B=128, size=1280, iters=5, warm=2, model_iters=3):
     """configs[4]: decode + per-image NMS on B x N candidate boxes (N = 100 800 at 1280^2), synthetic
     logits regime (ii) of SURVEY 8d: obj-logit ~ N(-5, 2^2), box/cls logits ~ N(0,1), seed 0.
     boxes/sec = B*N candidates consumed by decode + threshold + NMS per second (inputs resident in HBM)."""
@@ -156,7 +157,7 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5):
         if name.startswith("worst"):
             for t in logits:                       # regime (i) of SURVEY 8d: sigmoid(obj) ~ 0.5, (nearly) every box passes
                 t[..., 4] = (t[..., 4] + 5.0) * 0.5
-        for _ in range(2):
+        for _ in range(warm):
             boxes = cells_to_bboxes(logits, anchors, [8, 16, 32], is_pred=True, to_list=False)
             rows, idx, cnt = nms_batched(boxes, iou, thr, 300)
         torch.cuda.synchronize()
@@ -185,13 +186,13 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5):
         model.eval()
         x = torch.rand((B, 3, size, size), generator=g, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for _ in range(2):
+            for _ in range(warm):
                 o = model(x)
                 boxes = cells_to_bboxes(o, anchors, [8, 16, 32], is_pred=True, to_list=False)
                 rows, idx, cnt = nms_batched(boxes, 0.45, 0.25, 300)
             torch.cuda.synchronize()
             tf = td = tn = 0.0
-            for _ in range(3):
+            for _ in range(model_iters):
                 e0.record()
                 o = model(x)
                 e1.record()
@@ -201,9 +202,9 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5):
                 e3 = torch.cuda.Event(enable_timing=True)
                 e3.record()
                 torch.cuda.synchronize()
-                tf += e0.elapsed_time(e1) / 3
-                td += e1.elapsed_time(e2) / 3
-                tn += e2.elapsed_time(e3) / 3
+                tf += e0.elapsed_time(e1) / model_iters
+                td += e1.elapsed_time(e2) / model_iters
+                tn += e2.elapsed_time(e3) / model_iters
         model.train(True)
         model._engines = {}
         flops = B * FWD_GFLOP_PER_IMAGE_640 * (size / 640.0) ** 2
@@ -215,7 +216,8 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5):
                                "end_to_end_boxes_per_sec": round(B * N / ((tf + td + tn) * 1e-3)),
                                "kept_per_image": round(float(cnt.float().mean()), 1)}
     return {"workload": f"decode + NMS, batch {B} @ {size}x{size} ({N} candidate boxes/image), synthetic logits "
-                        f"(obj ~ N(-5,2^2)), max_detections 300 (BASELINE.json configs[4])", "unit": "boxes/s", **out}
+                        f"(obj ~ N(-5,2^2)), max_detections 300" + (" (BASELINE.json configs[4])" if (B, size) == (128, 1280) else ""),
+            "unit": "boxes/s", **out}
 
 
 def _guarded(name, fn):
@@ -374,6 +376,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-detect", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the backward pass instead of the bucketed, overlapped exchange")
+    # sizes of the untimed legs (defaults = BASELINE.json configs[1] / configs[4] / the CPU sample; tests/emu/dry_run_bench.py runs
+    # every leg at a tiny size on the CPU executor)
+    ap.add_argument("--fwd-shape", default="32x640", help="forward leg: batch x size")
+    ap.add_argument("--detect-shape", default="128x1280", help="detect leg: batch x size")
+    ap.add_argument("--cpu-shape", default="4x640", help="cpu_baseline leg: batch x size")
+    ap.add_argument("--leg-iters", type=int, default=0, help="iterations of the untimed legs (0 = their defaults; the dry run passes 1)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -533,13 +541,17 @@ def main():
         del step, images
         model._engines = {}
         torch.cuda.empty_cache()
-        out["forward"] = _guarded("forward", lambda: forward_leg(model, dev))
+        fb, fs = (int(v) for v in args.fwd_shape.split("x"))
+        db, ds = (int(v) for v in args.detect_shape.split("x"))
+        li = args.leg_iters
+        out["forward"] = _guarded("forward", lambda: forward_leg(model, dev, fb, fs, *((li, li) if li else ())))
         model._engines = {}
         torch.cuda.empty_cache()
-        out["detect"] = _guarded("detect", lambda: detect_leg(dev, model))
+        out["detect"] = _guarded("detect", lambda: detect_leg(dev, model, db, ds, *((li, li, li) if li else ())))
     if not args.no_cpu_baseline:
         # (rank 0's host cores; with N > 1 the other ranks wait at the exit barrier -- a gloo group with a two-hour timeout)
-        out["cpu_baseline"] = _guarded("cpu_baseline", lambda: cpu_baseline(world=world))
+        cb, cs = (int(v) for v in args.cpu_shape.split("x"))
+        out["cpu_baseline"] = _guarded("cpu_baseline", lambda: cpu_baseline(cb, cs, *((args.leg_iters,) if args.leg_iters else ()), world=world))
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(group=exit_group)

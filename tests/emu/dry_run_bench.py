@@ -31,9 +31,41 @@ with emulated():
     torch.Tensor.to = lambda self, *a, **k: ot(self, *[fix(x) for x in a], **{kk: fix(v) for kk, v in k.items()})
     torch.nn.Module.to = lambda self, *a, **k: om(self, *[fix(x) for x in a], **k)
     torch.tensor = lambda *a, **k: tt(*a, **{kk: fix(v) for kk, v in k.items()})
-    if n == 1:
+    for name in ("randn", "rand", "zeros", "ones", "empty", "full", "arange", "randint"):
+        setattr(torch, name, (lambda f: lambda *a, **k: f(*a, **{kk: fix(v) for kk, v in k.items()}))(getattr(torch, name)))
+    import torch.distributed.tensor  # noqa: F401  (its annotations evaluate `torch.Generator | None` at import: before the stand-in)
+    og = torch.Generator
+    torch.Generator = lambda device="cpu": og(device=fix(device))
+
+    # stand-ins of HIP events and streams (launches are synchronous here): an event is the host clock at record()
+    import time
+
+    class Ev:
+        def __init__(self, enable_timing=False): self.t = 0.0
+        def record(self, stream=None): self.t = time.perf_counter()
+        def elapsed_time(self, other): return max((other.t - self.t) * 1e3, 1e-6)
+        def synchronize(self): pass
+        def wait(self, *a): pass
+        def query(self): return True
+
+    class St:
+        cuda_stream = 0
+        def __init__(self, *a, **k): pass
+        def wait_event(self, e): pass
+        def wait_stream(self, s): pass
+        def synchronize(self): pass
+        def record_event(self, e=None):
+            e = e or Ev(); e.record(); return e
+    import contextlib
+    torch.cuda.Event, torch.cuda.Stream = Ev, St
+    torch.cuda.current_stream = lambda *a, **k: St()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    if n == 1 and "--no-smoke" not in sys.argv:
         import yolov5m_amd.smoke as S
         S.run()
-    sys.argv = ["bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64", "--no-graph", "--no-roofline",
-                "--no-detect", "--no-cpu-baseline"]
+    # every untimed leg of bench.py too (roofline = profile_step with an event pair per launch, forward, detect, cpu_baseline), each
+    # at a tiny size: a Python error in any of them shows here, not in the driver's round-end run
+    B_, S_ = os.environ.get("Y5M_DRY_SHAPE", "2x64").split("x")
+    sys.argv = ["bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "1", "--leg-iters", "1", "--batch", B_, "--size", S_, "--no-graph",
+                "--fwd-shape", f"{B_}x{S_}", "--detect-shape", f"{B_}x{S_}", "--cpu-shape", f"1x{S_}"]
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")

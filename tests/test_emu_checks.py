@@ -103,3 +103,26 @@ def test_round4_kernel_forms_green_on_the_executor():
     assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-800:]
     c = _child('from yolov5m_amd import ops\n    T.test_conv_wgrad_rows_kernel((1, 48, 11, 13, 96, 3, 2, 1))\n    assert ops.LAST_WGRAD_KERNEL.endswith(",0>"), ops.LAST_WGRAD_KERNEL')
     assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-800:]
+
+
+def test_bench_untimed_legs_execute_on_the_executor():
+    """bench.py's whole main() -- timed loop, then the roofline (an event pair around every launch of profile_step), forward, detect and
+    cpu_baseline legs -- at a tiny size on the CPU executor (tests/emu/dry_run_bench.py; stand-ins for HIP events / streams): a Python
+    error in a leg the driver only meets at round end shows up here. And a leg that does fail costs its own object, not the line."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "dry_run_bench.py"), "1", "--no-smoke"],
+                       env=dict(os.environ, Y5M_EMU_THREADS="4"), capture_output=True, text=True, timeout=1500)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "forward", "detect", "kernel_forms"):
+        assert k in d, k
+    for leg in ("roofline", "forward", "detect", "cpu_baseline"):
+        assert "error" not in d[leg], (leg, d[leg])
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["cpu_baseline"]["kind"] == "port"
+    assert "BASELINE.json" not in d["config"]["workload"].split("(")[-1] or "NOT a BASELINE" in d["config"]["workload"]
+    sys.path.insert(0, ROOT)
+    import bench
+    g = bench._guarded("broken", lambda: 1 / 0)
+    assert g == {"error": "broken leg failed: ZeroDivisionError: division by zero"}

@@ -168,7 +168,8 @@ def test_plan_cache_retries_after_oom_outside_the_handler(monkeypatch):
 
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), Y5M_EMU_THREADS="4")
+                      LOCAL_RANK=str(rank), Y5M_EMU_THREADS=str(max(1, 8 // world)))
+    torch.set_num_threads(max(1, 8 // world))
     sys.path.insert(0, HERE)
     import torch.distributed as dist
     from emu.harness import emulated
@@ -191,16 +192,26 @@ def _dp_worker(rank, world, port, q):
             parallel.broadcast_parameters(m)
             hook = parallel.GradAllReduce(world)
             # use_graph=True: the harness records the per-segment captures, the second step REPLAYS them with a bucket behind each
-            step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=True, grad_hook=hook, overlap=True)
+            # (world 8: one eager overlapped step -- eight ranks share this machine's eight cores)
+            graphs = world <= 2
+            launched = []
+            real_launch = hook.launch
+            hook.launch = lambda flat, lo, hi: (launched.append((lo, hi)), real_launch(flat, lo, hi))[1]
+            step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=graphs, grad_hook=hook, overlap=True)
             p0 = m.flat_params.clone()
             step.step(x, t)
-            segs = step._fb_graphs[next(iter(step._fb_graphs))]
-            assert segs[2] == "segments" and len(segs[1]) == 3 and all(len(g.ops) > 0 for g in segs[1]) and len(step._opt_graph.ops) == 3
             cuts = m._engines[next(iter(m._engines))]._cuts
+            # three buckets in backward order (head first), contiguous, covering the whole flat buffer: 84.76 MB
+            n = m.flat_grads.numel()
+            assert len(launched) == 3 and launched[0][1] == n and launched[-1][0] == 0, launched
+            assert all(a[0] == b[1] for a, b in zip(launched, launched[1:])) and sum(hi - lo for lo, hi in launched) * 4 == 84762228, launched
             gerr = float((m.flat_grads - ref).abs().max() / ref.abs().max())
-            p1 = m.flat_params.clone()
-            step.step(x, t)                                  # replayed segments
-            assert float((m.flat_params - p1).abs().max()) > 0 and int(step.d_step) == 2
+            if graphs:
+                segs = step._fb_graphs[next(iter(step._fb_graphs))]
+                assert segs[2] == "segments" and len(segs[1]) == 3 and all(len(g.ops) > 0 for g in segs[1]) and len(step._opt_graph.ops) == 3
+                p1 = m.flat_params.clone()
+                step.step(x, t)                                  # replayed segments
+                assert float((m.flat_params - p1).abs().max()) > 0 and int(step.d_step) == 2
             mine = m.flat_params.clone()
             others = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(others, mine)
@@ -215,7 +226,11 @@ def _dp_worker(rank, world, port, q):
         raise
 
 
-def test_dp_overlapped_schedule_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_dp_overlapped_schedule_gloo_ranks(world):
+    """world 2: eager warm-up + captured segments + a replayed step. world 8 (the driver's SCALE run is the first time the
+    data-parallel path meets eight ranks on hardware): make_buckets / grad_cuts / broadcast_parameters / the bucketed exchange with
+    EIGHT gloo ranks, one overlapped step each on its own batch."""
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -224,10 +239,10 @@ def test_dp_overlapped_schedule_two_ranks_gloo():
     emu_lib_path()                                     # build once, before the ranks race for it
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in range(2)]
+    res = [q.get(timeout=1500) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
     for rank, ncuts, gerr, same, moved, err in res:
