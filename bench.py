@@ -535,6 +535,15 @@ def main():
                            # approximate: 5 plain steps against args.steps overlapped ones, a second NativeTrainStep (fresh Adam
                            # state, its own captured graphs) on the same model
                            "overlap_gain_ms_per_step_approx": round(plain["ms_per_step"] - ms, 3) if plain else None}
+    def step_bytes():
+        # the plan's algorithmic HBM bytes (every operand of every launch moved once: Engine.algorithmic_bytes, pinned by
+        # tests/test_traffic_cpu.py) against the step time: the whole step's distance from the HBM roofline
+        r = step.algorithmic_bytes(model._engine_for(images))
+        rate = r["total_bytes"] / (ms * 1e-3) / 1e9
+        top = sorted(r["by_kind"].items(), key=lambda kv: -kv[1][0])[:6]
+        return {"algorithmic_GB_per_step": round(r["total_bytes"] / 1e9, 3), "GBps_at_step_time": round(rate, 1),
+                "frac_of_hbm_peak": round(rate / PEAK_HBM_GBPS, 4), "GB_by_kind": {k: round(v[0] / 1e9, 3) for k, v in top}}
+    out["step_bytes"] = _guarded("step_bytes", step_bytes)
     if not args.no_roofline:
         out["roofline"] = _guarded("roofline", lambda: roofline_leg(step, model, images, targets, args.dtype))
     if world == 1 and not args.no_detect:

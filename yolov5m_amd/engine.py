@@ -30,9 +30,20 @@ from ._lib import (ConvArgs, WgradArgs, EPI_RAW_STATS, EPI_AFFINE_ACT, EPI_HEAD,
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 
 
-def _kind(fn, kind):
-    """tag a launch closure with its kernel family (used by the live per-family timing in bench.py)"""
+def _kind(fn, kind, traffic=None):
+    """tag a launch closure with its kernel family (used by the live per-family timing in bench.py) and, where the plan knows
+    them, its algorithmic HBM bytes (see _traffic)"""
     fn.kind = kind
+    if traffic is not None:
+        fn.traffic = tuple(int(v) for v in traffic)
+    return fn
+
+
+def _traffic(fn, act_r=0, act_w=0, par_r=0, par_w=0):
+    """ALGORITHMIC HBM bytes of one launch-list entry -- every operand moved once, whatever the kernel re-reads through L2:
+    (activation bytes read, activation bytes written: both proportional to the batch; parameter / gradient / workspace bytes
+    read, written: independent of it). Engine.algorithmic_bytes() sums them; tests/test_traffic_cpu.py pins the step's total."""
+    fn.traffic = (int(act_r), int(act_w), int(par_r), int(par_w))
     return fn
 
 
@@ -103,6 +114,7 @@ class Engine:
         self.dev = model.flat_params.device
         self.CH = 8 if dtype == BF16 else 4
         self.BK = 64 if dtype == BF16 else 32
+        self.esz = 2 if dtype == BF16 else 4            # bytes of an activation element
         self.nc, self.naxs = model.head.nc, model.head.naxs
         self.nch = 5 + self.nc
         self.fwd, self.bwd = [], []
@@ -186,7 +198,24 @@ class Engine:
         def fn(a=a):
             _lib.check(L.y5m_conv(ctypes.byref(a), dt, _lib.stream_ptr()), "y5m_conv")
         fn.kind = "conv_igemm"
+        _traffic(fn, *self._conv_traffic([a]))
         lst.append((fn, ()))
+
+    def _conv_traffic(self, descs):
+        """algorithmic bytes of one y5m_conv / y5m_conv_multi launch: the input tensor once (the problems of a multi launch --
+        the parity classes of a stride-2 data gradient -- read the SAME input), every output element once (+ once more where
+        the epilogue accumulates onto it or takes a residual / lazy accumulation source), the packed weights once"""
+        esz = self.esz
+        a0 = descs[0]
+        act_r = a0.B * a0.Hin * a0.Win * a0.Cin * esz
+        act_w = par_r = 0
+        for a in descs:
+            out = a.M * a.N * (4 if a.epi == EPI_HEAD else esz)
+            act_w += out
+            if a.accumulate or a.res:
+                act_r += a.M * a.N * esz
+            par_r += a.N * a.K * esz
+        return act_r, act_w, par_r, 0
 
     # ------------------------------------------------------------------ building blocks
     def _cbl(self, name, x, cout, k, s, p, dest=None, res=None, stem=False):
@@ -261,6 +290,8 @@ class Engine:
                     _lib.check(L.y5m_bn_act(_lib.ptr(lay.y), lay.cout, bn[0].data_ptr(), bn[1].data_ptr(),
                                             res.ptr if res is not None else None, res.ld if res is not None else 0,
                                             dest.ptr, dest.ld, M, lay.cout, ACT_SILU, dt, st()), "y5m_bn_act")
+            _traffic(apply, M * cout * self.esz * (2 if res is not None else 1), M * cout * self.esz, 8 * cout, 16 * cout)
+            apply.kind = "apply_fused" if self.fuse_f else "apply"
             self.fwd.append((apply, ()))
             self._cbl_backward(lay, P)
         else:
@@ -346,7 +377,8 @@ class Engine:
                 else:
                     ops.extend(self._flush_lazy(lay.res))
                     ops.append((_kind(lambda rg=rg, dz=dz, acc=acc: _lib.check(
-                        L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), "add"), ()))
+                        L.y5m_add(dz.ptr, dz.ld, rg.ptr, rg.ld, lay.M, lay.cout, acc, dt, st()), "y5m_add"), "add",
+                        (lay.M * lay.cout * self.esz * (2 if acc else 1), lay.M * lay.cout * self.esz, 0, 0)), ()))
             # BN + SiLU backward -> dy (scratch), dgamma, dbeta
             ops.extend(_as_list(self._bn_backward_op(lay, P, dz, scratch.data_ptr(), lay.cout)))
             # weight gradient (packed f32, atomics into the zeroed gw buffer)
@@ -405,10 +437,11 @@ class Engine:
                         ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(a), ctypes.sizeof(ConvArgs))
                     lay.dgrad_multi = arr
                     ops.append((_kind(lambda arr=arr: _lib.check(L.y5m_conv_multi(arr, len(arr), dt, st()), "y5m_conv_multi(dgrad)"),
-                                      "conv_igemm"), ()))
+                                      "conv_igemm", self._conv_traffic(lay.dgrad_args)), ()))
                 else:
                     for a in lay.dgrad_args:
-                        ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm"), ()))
+                        ops.append((_kind(lambda a=a: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(dgrad)"), "conv_igemm",
+                                          self._conv_traffic([a])), ()))
                 self._written(lay.x)
             return ops
         self._bwd_stack.append(backward)
@@ -439,11 +472,13 @@ class Engine:
             return (_kind(lambda: _lib.check(
                 L.y5m_bn_bwd_fused(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                                    bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0,
-                                   scratch_ptr, lddy, accp, dt, st()), "y5m_bn_bwd_fused"), "bn_bwd(reduce + apply)"), ())
+                                   scratch_ptr, lddy, accp, dt, st()), "y5m_bn_bwd_fused"), "bn_bwd(reduce + apply)",
+                          (4 * lay.M * lay.cout * self.esz, lay.M * lay.cout * self.esz, 16 * lay.cout, 8 * lay.cout)), ())
         return (_kind(lambda: _lib.check(
             L.y5m_bn_bwd(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                          bn[3].data_ptr(), lay.M, lay.cout, ACT_SILU, _lib.ptr(P["gg"]), _lib.ptr(P["gb"]), 0, scratch_ptr,
-                         lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), "bn_bwd(reduce + apply)"), ())
+                         lddy, _lib.ptr(self.bnws), self._bnws_bytes, dt, st()), "y5m_bn_bwd"), "bn_bwd(reduce + apply)",
+                      (4 * lay.M * lay.cout * self.esz, lay.M * lay.cout * self.esz, 16 * lay.cout, 8 * lay.cout)), ())
 
     def _bwd_pw_ops(self, x, y_ptr, y_ld, wd, segs, M, N):
         """launch list entries of the fused pointwise backward (y5m_bwd_pw) of one 1x1 CBL -- or of a merged C3 pair: `segs` is
@@ -490,12 +525,15 @@ class Engine:
                 _lib.check(L.y5m_bn_bwd_fused_phase(dz.ptr, dz.ld, lay.y_ptr, lay.y_ld, bn[0].data_ptr(), bn[1].data_ptr(),
                                                     bn[2].data_ptr(), bn[3].data_ptr(), M, lay.cout, ACT_SILU, None, None, 0,
                                                     None, 0, sg.acc, dt, st(), 1), "y5m_bn_bwd_fused_phase(reduce)")
-            ops.append((_kind(reduce, "bn_reduce"), ()))
+            ops.append((_kind(reduce, "bn_reduce", (2 * M * lay.cout * self.esz, 0, 12 * lay.cout, 0)), ()))
             self._grad_done.append((lay.name, P["gw"].data_ptr()))
         def fused(a=a):
             _lib.check(L.y5m_bwd_pw(ctypes.byref(a), dt, st()), "y5m_bwd_pw")
         fused.bp = a
-        ops.append((_kind(fused, "bwd_pw"), ()))
+        # dz and y (N channels each) and x read, dx written (+ its accumulation source read); the transposed weights read,
+        # dW added into the flat gradient
+        ops.append((_kind(fused, "bwd_pw", (M * (2 * N + x.C * (2 if (a.accumulate or a.res) else 1)) * self.esz, M * x.C * self.esz,
+                                            N * x.C * self.esz, N * x.C * 4)), ()))
         self._direct_wgrads += 1
         self._written(x)
         return ops
@@ -534,7 +572,10 @@ class Engine:
         def unpack():
             _lib.check(L.y5m_unpack_wgrad(a.dwgt, lay.cout, lay.cin_real, lay.k, lay.k, 2, lay.ldgw, P["gw"].data_ptr(), st()),
                        "y5m_unpack_wgrad")
-        ops += [(_kind(reduce, "bn_reduce"), ()), (_kind(fused, "bwd_stem"), ()), (_kind(unpack, "unpack"), ())]
+        dw = lay.cout * lay.ldgw * 4
+        ops += [(_kind(reduce, "bn_reduce", (2 * lay.M * lay.cout * self.esz, 0, 12 * lay.cout, 0)), ()),
+                (_kind(fused, "bwd_stem", (lay.M * (2 * lay.cout + x.C) * self.esz, 0, 20 * lay.cout, dw)), ()),
+                (_kind(unpack, "unpack", (0, 0, dw, dw)), ())]
         self._grad_done.append((lay.name, P["gw"].data_ptr()))
         return ops
 
@@ -565,8 +606,9 @@ class Engine:
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
         src, g = act.lazy, act.grad
         act.lazy = None
+        nb = act.B * act.H * act.W * act.C * self.esz
         return [(_kind(lambda: _lib.check(L.y5m_add(src.ptr, src.ld, g.ptr, g.ld, act.B * act.H * act.W, act.C, 0, dt, st()),
-                                          "y5m_add(lazy)"), "add"), ())]
+                                          "y5m_add(lazy)"), "add", (nb, nb, 0, 0)), ())]
 
     def _c3(self, name, x, cout, width, depth, backbone, dest=None):
         """reference model.py:54-92"""
@@ -689,6 +731,8 @@ class Engine:
                                               BN_MOMENTUM, BN_EPS, 1, bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(),
                                               bn[3].data_ptr(), None, 0, lay.z.ptr, lay.z.ld, M, cout, ACT_SILU, dt, st()),
                            "y5m_bn_act_fused")
+            for f_ in (apply, apply_fused):
+                _traffic(f_, M * cout * self.esz, M * cout * self.esz, 8 * cout, 16 * cout)
             if self.fuse_f:
                 self.fwd.append((apply_fused, ()))
             else:
@@ -753,7 +797,7 @@ class Engine:
                 g.epi, g.act, g.accumulate, g.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
                 self._written(x)
                 ops.append((_kind(lambda g=g: _lib.check(L.y5m_conv(ctypes.byref(g), dt, st()), "y5m_conv(pair dgrad)"),
-                                  "conv_igemm"), ()))
+                                  "conv_igemm", self._conv_traffic([g])), ()))
             return ops
         self._bwd_stack.append(backward)
         return destA
@@ -768,7 +812,7 @@ class Engine:
         sppfws = torch.zeros((L.y5m_sppf_pool_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
         self.fwd.append((_kind(lambda: _lib.check(L.y5m_sppf_pool(sl[0].ptr, cat.ld, x.B, x.H, x.W, c_, sl[1].ptr, sl[2].ptr,
                                                                  sl[3].ptr, _lib.ptr(sppfws), sppfws.numel(), dt, st()),
-                                                  "y5m_sppf_pool"), "pool"), ()))
+                                                  "y5m_sppf_pool"), "pool", (x.M * c_ * self.esz, 3 * x.M * c_ * self.esz, 0, 0)), ()))
         if self.training:
             poolws = torch.zeros((L.y5m_maxpool5_bwd_workspace_bytes(x.B, x.H, x.W, c_),), dtype=torch.uint8, device=self.dev)
             for _ in range(3):
@@ -784,7 +828,7 @@ class Engine:
                     ops.append((_kind(lambda lvl=lvl: _lib.check(
                         L.y5m_maxpool5_bwd(sl[lvl].ptr, cat.ld, g[lvl + 1].ptr, g[lvl + 1].ld, x.B, x.H, x.W, c_,
                                            g[lvl].ptr, g[lvl].ld, 1, _lib.ptr(poolws), poolws.numel(), dt, st()),
-                        "y5m_maxpool5_bwd"), "pool"), ()))
+                        "y5m_maxpool5_bwd"), "pool", (3 * x.M * c_ * self.esz, x.M * c_ * self.esz, 0, 0)), ()))
                 return ops
             self._bwd_stack.append(backward)
         return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0)
@@ -793,7 +837,7 @@ class Engine:
         """reference model.py:225 (nearest x2), written straight into its concat slice"""
         L, dt, st = self.L, self.dtype, _lib.stream_ptr
         self.fwd.append((_kind(lambda: _lib.check(L.y5m_upsample2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, dst.ptr, dst.ld, dt, st()),
-                                                  "y5m_upsample2x"), "upsample"), ()))
+                                                  "y5m_upsample2x"), "upsample", (x.M * x.C * self.esz, 4 * x.M * x.C * self.esz, 0, 0)), ()))
         if self.training:
             self._consume(x)
 
@@ -804,7 +848,8 @@ class Engine:
                 x.gw = True
                 return pre + [(_kind(lambda: _lib.check(L.y5m_upsample2x_bwd(dst.grad.ptr, dst.grad.ld, x.B, x.H, x.W, x.C,
                                                                        x.grad.ptr, x.grad.ld, acc, dt, st()),
-                                                  "y5m_upsample2x_bwd"), "upsample"), ())]
+                                                  "y5m_upsample2x_bwd"), "upsample",
+                                     ((4 + acc) * x.M * x.C * self.esz, x.M * x.C * self.esz, 0, 0)), ())]
             self._bwd_stack.append(backward)
 
     def _head(self, i, x):
@@ -855,7 +900,10 @@ class Engine:
                     else:
                         _lib.check(L.y5m_head_grad_pack(_lib.ptr(lay.gout), x.B, self.naxs, x.H, x.W, self.nch, _lib.ptr(scratch),
                                                         ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack")
-                ops.append((_kind(pack, "head_pack"), ()))
+                # sparse form (the loss wrote the target rows + a compact objectness plane): one f32 per cell read; dense form: the
+                # whole f32 gradient; either way the bf16 operand rows of the two GEMMs behind it are written in full
+                sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
+                ops.append((_kind(pack, "head_pack", (M * self.naxs * 4 * (1 if sparse else self.nch), M * ldp * self.esz, 0, 4 * N)), ()))
                 wa = WgradArgs()
                 wa.zeros = _lib.zero_page(self.dev).data_ptr()
                 wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
@@ -879,7 +927,8 @@ class Engine:
                 a.Hout, a.Wout, a.ldout, a.osy, a.osx, a.ooy, a.oox = x.H, x.W, x.grad.ld, 1, 1, 0, 0
                 a.epi, a.act, a.accumulate, a.Np = EPI_DGRAD, ACT_NONE, acc, wd.shape[0]
                 lay.dgrad_args = [a]
-                ops.append((_kind(lambda: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(head dgrad)"), "conv_igemm"), ()))
+                ops.append((_kind(lambda: _lib.check(L.y5m_conv(ctypes.byref(a), dt, st()), "y5m_conv(head dgrad)"), "conv_igemm",
+                                  self._conv_traffic([a])), ()))
                 return ops
             self._bwd_stack.append(backward)
         self.heads.append(lay)
@@ -899,7 +948,7 @@ class Engine:
         self.x_in = torch.zeros((B, 3, H, W), dtype=torch.float32, device=self.dev)
         s2d = self._new_act(B, H // 2, W // 2, 16, need_grad=False)
         self.fwd.append((_kind(lambda: _lib.check(L.y5m_s2d_input(_lib.ptr(self.x_in), B, H, W, s2d.ptr, dt, _lib.stream_ptr()),
-                                                  "y5m_s2d_input"), "input"), ()))
+                                                  "y5m_s2d_input"), "input", (B * 3 * H * W * 4, B * (H // 2) * (W // 2) * 16 * self.esz, 0, 0)), ()))
         f = first_out
         # concat buffers of the PANet joins (model.py:226, :230); producers write their slices in place
         cat1 = self._new_act(B, H // 16, W // 16, 16 * f)     # [up(neck0) | backbone6]
@@ -942,7 +991,7 @@ class Engine:
             self.accf = torch.zeros((self._accf,), dtype=torch.float64, device=self.dev)
             for a, off in self._acc_users:
                 a.bn_acc = self.accf.data_ptr() + 8 * off
-            self.fwd.insert(0, (_kind(lambda: self.accf.zero_(), "fill"), ()))
+            self.fwd.insert(0, (_kind(lambda: self.accf.zero_(), "fill", (0, 0, 0, 8 * self._accf)), ()))
         if self.training:
             self.scratch2 = [torch.zeros((self._scratch_elems,), dtype=self.tdt, device=self.dev) for _ in range(self.nslots)]
             self.scratch = self.scratch2[0]
@@ -951,8 +1000,9 @@ class Engine:
             self._accb_base = (self._gw_floats + 1) // 2 * 2
             self.gw = torch.zeros((self._accb_base + (2 * self._accb if self.fuse_b else 0),), dtype=torch.float32, device=self.dev)
             # expand the backward stack in reverse order; plan-time gradient-written flags
-            self.bwd.append((_kind(lambda: self.gw.zero_(), "fill"), ()))
-            self.bwd.append((_kind(lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, "fill"), ()))
+            self.bwd.append((_kind(lambda: self.gw.zero_(), "fill", (0, 0, 0, 4 * self.gw.numel())), ()))
+            self.bwd.append((_kind(lambda: self.model.flat_grads.zero_() if self._direct_wgrads else None, "fill",
+                                   (0, 0, 0, 4 * self.model.flat_grads.numel())), ()))
             # bwd_marks[i] = (op index after which unit i's parameter gradients are final, unit name,
             # device address of its weight gradient inside the flat buffer) -- in backward order. The marks are taken from the
             # FINAL order of the list (after the reorder below): a unit's mark is one past the last of ITS OWN ops, wherever
@@ -1056,6 +1106,11 @@ class Engine:
             self._pending[slot] = done
         run.kind = "wgrad"
         run.wa = wa                     # the y5m_wgrad_args of this launch (bench.py: per-kernel roofline)
+        if wa is not None:
+            # dy and x once, the packed f32 gradient written (atomics), each unpack launch behind it reads and writes it once
+            dw = wa.N * wa.th * wa.tw * wa.C * 4
+            u = 1 if len(fns) > 1 else 0
+            _traffic(run, (wa.M * wa.N + wa.B * wa.Hin * wa.Win * wa.C) * self.esz, 0, dw * u, dw * (1 + u))
         return run
 
     def _join_op(self, slot, final=False):
@@ -1130,6 +1185,9 @@ class Engine:
             _lib.check(L.y5m_pack_weights_batched(_lib.ptr(self._pack_table), n, tot, dt, _lib.stream_ptr()),
                        "y5m_pack_weights_batched")
         pack_all.kind = "pack_weights"
+        # every master weight a job reads (f32) and every packed element it writes
+        masters = {j.src: j.Cout * j.Cin * j.KH * j.KW * 4 for j in jobs}
+        _traffic(pack_all, 0, 0, sum(masters.values()), tot * self.esz)
         self.pack = [(pack_all, ())] + rest
         if self._fold_jobs:
             fj, start = [], 0
@@ -1170,6 +1228,33 @@ class Engine:
             if timeline is not None:
                 e1.record()
                 timeline.append((getattr(fn, "kind", getattr(fn, "__name__", "other")), e0, e1))
+
+    def algorithmic_bytes(self):
+        """The plan's ALGORITHMIC HBM traffic: every operand of every launch-list entry moved once (see _traffic), summed per
+        list and per kernel family. Returns {"pack" | "forward" | "backward": {"act_read", "act_written", "par_read",
+        "par_written", "launches", "by_kind": {kind: [act_read, act_written, par_read, par_written, launches]}}, "B": batch}.
+        The act_* bytes are proportional to the batch, the par_* bytes (weights, weight gradients, BatchNorm rows, fills) do
+        not depend on it: total(B') = act * B' / B + par. What L2 absorbs or re-reads is NOT in here -- the PMC counters'
+        job (tools/pmc_bench.sh); this is the floor a launch list can be held against."""
+        out = {"B": self.B}
+        for name, lst in (("pack", self.pack), ("forward", self.fwd), ("backward", self.bwd if self.training else [])):
+            tot, by = [0, 0, 0, 0, 0], {}
+            for fn, _args in lst:
+                t = getattr(fn, "traffic", None)
+                kind = getattr(fn, "kind", getattr(fn, "__name__", "other"))
+                if t is None:
+                    if kind not in ("join", "finalize", "fold_all"):
+                        raise AssertionError(f"launch-list entry of kind {kind!r} carries no traffic figure")
+                    t = (0, 0, 0, 0)
+                row = by.setdefault(kind, [0, 0, 0, 0, 0])
+                for i in range(4):
+                    row[i] += t[i]
+                    tot[i] += t[i]
+                row[4] += 1
+                tot[4] += 1
+            out[name] = {"act_read": tot[0], "act_written": tot[1], "par_read": tot[2], "par_written": tot[3], "launches": tot[4],
+                         "by_kind": by}
+        return out
 
     def conv_flops(self):
         """Algorithmic FLOPs (2*MAC on the REAL layer shapes) of one forward

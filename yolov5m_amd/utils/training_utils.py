@@ -240,6 +240,35 @@ class NativeTrainStep:
         from ..engine import Engine
         Engine._run([(opt_ops, ())], timeline)
 
+    def algorithmic_bytes(self, eng, B=None):
+        """ALGORITHMIC HBM bytes of one whole train step on plan `eng` (Engine.algorithmic_bytes + the loss and the optimizer),
+        optionally rescaled to batch B (the activation bytes are proportional to the batch, the parameter bytes are not).
+        Loss (sparse head gradient): one objectness logit per cell read and one objectness gradient written, f32, plus the
+        85-float rows of the matched cells (about three per label); optimizer: the gradient once for the norm, then p, g, m, v
+        read and p, m, v written, f32."""
+        eb = eng.algorithmic_bytes()
+        scale = (B / eng.B) if B else 1.0
+        cells = sum(o.shape[1] * o.shape[2] * o.shape[3] for o in eng.outs) * eng.B
+        rows = 3 * self.nt_max
+        n = self.model.flat_params.numel()
+        lists = {k: dict(eb[k]) for k in ("pack", "forward", "backward")}
+        lists["loss"] = {"act_read": cells * 4 + rows * 85 * 4, "act_written": cells * 4 + rows * 85 * 4, "par_read": 0, "par_written": 0,
+                         "launches": 1, "by_kind": {}}
+        lists["optimizer"] = {"act_read": 0, "act_written": 0, "par_read": 5 * 4 * n, "par_written": 3 * 4 * n, "launches": 2, "by_kind": {}}
+        act = sum(v["act_read"] + v["act_written"] for v in lists.values())
+        par = sum(v["par_read"] + v["par_written"] for v in lists.values())
+        by_kind = {}
+        for v in lists.values():
+            for k, r in v["by_kind"].items():
+                row = by_kind.setdefault(k, [0.0, 0])
+                row[0] += (r[0] + r[1]) * scale + r[2] + r[3]
+                row[1] += r[4]
+        by_kind["loss"] = [(lists["loss"]["act_read"] + lists["loss"]["act_written"]) * scale, 1]
+        by_kind["optimizer"] = [float(lists["optimizer"]["par_read"] + lists["optimizer"]["par_written"]), 2]
+        return {"B": B or eng.B, "activation_bytes": act * scale, "parameter_bytes": float(par), "total_bytes": act * scale + par,
+                "lists": {k: (v["act_read"] + v["act_written"]) * scale + v["par_read"] + v["par_written"] for k, v in lists.items()},
+                "by_kind": by_kind}
+
     def load_inputs(self, images, targets):
         eng = self.model._engine_for(images)
         if images.data_ptr() != eng.x_in.data_ptr():       # a loader that fills input_buffer() directly skips this copy
