@@ -111,10 +111,105 @@ def audit(path):
             return (len(ll), mix, dep, full, loads)
         loops = [summarise(ll) for ll in loops]
         loops.sort(key=lambda t: -t[0])
+        steady = steady_paths(body)
         granule = (md["vgpr"] + 7) // 8 * 8              # (.vgpr_count is the unified total on gfx90a+: arch VGPRs + AGPRs)
         waves = min(8, 512 // max(granule, 8))
-        rows.append((pretty[n], md, waves, len(ops), tot, loops[:2], sum(1 for o in ops if o.startswith("v_div_fixup"))))
+        rows.append((pretty[n], md, waves, len(ops), tot, loops[:2], sum(1 for o in ops if o.startswith("v_div_fixup")), steady[:2]))
     return rows
+
+
+def steady_paths(body):
+    """The STEADY-STATE iteration of every loop that holds MFMAs: the static loop mix counts both sides of every branch (a
+    persistent kernel's epilogue sits inside its unit loop and is taken once per tile), so for each loop header this finds the
+    cheapest cycle header -> ... -> header, in instructions, that passes through every basic block of the loop that issues
+    MFMAs or fetches / stages operands (buffer_load_dwordx4, ds_write_b128), and returns its instruction mix. Basic blocks are split at labels AND behind every branch; edges are the branch
+    targets and the fall-through. Returns [(instructions, mix, full vmcnt(0) waits)] sorted by MFMA count."""
+    import heapq
+    blocks = []                    # [label or None, loop note, instructions]
+    note = ""
+    for l in body.splitlines():
+        st = l.strip()
+        m_ = re.match(r"^(\.LBB\d+_\d+):(.*)$", st)
+        if m_:
+            note = m_.group(2)
+            blocks.append([m_.group(1), note, []])
+            continue
+        if not blocks:
+            blocks.append([None, "", []])
+        if st.startswith(";"):
+            if "Loop" in st:
+                blocks[-1][1] += " " + st
+                note = blocks[-1][1]
+            continue
+        if not st or st.startswith("."):
+            continue
+        blocks[-1][2].append(st)
+        if st.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+            blocks.append([None, note, []])            # the instructions behind a branch are a new basic block of the same loop
+    idx = {b[0]: i for i, b in enumerate(blocks) if b[0]}
+    succ = []
+    for i, (lbl, _n, ins) in enumerate(blocks):
+        out = []
+        last = ins[-1] if ins else ""
+        if last.startswith(("s_cbranch", "s_branch")):
+            t = last.split()[-1]
+            if t in idx:
+                out.append(idx[t])
+        if not last.startswith(("s_branch", "s_endpgm")) and i + 1 < len(blocks):
+            out.append(i + 1)
+        succ.append(out)
+    res = []
+    for h, (lbl, n_, _ins) in enumerate(blocks):
+        if not lbl or "Loop Header" not in n_:
+            continue
+        name_ = lbl[2:]
+        # (a loop's latch may be laid out IN FRONT of its header: every block annotated with the header's name belongs to it)
+        members = {h} | {j for j, b in enumerate(blocks) if re.search(r"(Header=|Parent Loop )" + name_ + r"\b", b[1])}
+        need = need_mfma = [j for j in sorted(members) if any(a.startswith("v_mfma") for a in blocks[j][2])]
+        if not need:
+            continue
+        # ... and through every block that STAGES operands (16-byte LDS stores): the prefetch of the next tile sits behind an
+        # `if (more)` that only the last iteration skips, and the cheapest cycle would skip it too
+        # (same for the 16-byte buffer loads that fetch them; the kernels' epilogues use global_load / global_store)
+        need = sorted(set(need) | {j for j in members if any(a.startswith(("ds_write_b128", "buffer_load_dwordx4")) for a in blocks[j][2])})
+
+        def shortest(src, dst):
+            dist, heap = {src: 0}, [(0, src, [src])]
+            while heap:
+                d, u, path = heapq.heappop(heap)
+                if u == dst and len(path) > 1:
+                    return d, path
+                if d > dist.get(u, 1 << 30):
+                    continue
+                for v in succ[u]:
+                    if v not in members:
+                        continue
+                    nd = d + len(blocks[v][2])
+                    if nd < dist.get(v, 1 << 30) or v == dst:
+                        if v != dst:
+                            dist[v] = nd
+                        heapq.heappush(heap, (nd, v, path + [v]))
+            return None, None
+        def cycle(req):
+            stops = [h] + [j for j in req if j != h] + [h]
+            path = [h]
+            for a, b in zip(stops, stops[1:]):
+                d, p_ = shortest(a, b)
+                if p_ is None:
+                    return None
+                path += p_[1:]
+            return path
+        path = cycle(need) or cycle(need_mfma)          # (staging blocks that no single cycle visits in layout order: MFMA blocks only)
+        if path is None:
+            continue
+        ins = [a for j in path[:-1] for a in blocks[j][2]]
+        mix = {}
+        for a in ins:
+            k = classify(a.split()[0])
+            mix[k] = mix.get(k, 0) + 1
+        res.append((len(ins), mix, sum(1 for a in ins if a.startswith("s_waitcnt vmcnt(0)"))))
+    res.sort(key=lambda t: -t[1].get("mfma", 0))
+    return res
 
 
 def main():
@@ -122,10 +217,12 @@ def main():
     print("# tools/isa_audit.py -- hipcc --offload-arch=gfx950 -O3 of yolov5m_amd/csrc at HEAD (static: no GPU involved)")
     print("# per kernel: VGPRs (of which AGPRs) / SGPRs, spills (v/s), scratch B, static LDS B, waves per SIMD by registers, instructions;")
     print("# then its one or two largest loops: instruction count and mix (STATIC: both sides of every branch), `dep` = loads directly followed by")
-    print("# s_waitcnt vmcnt(0), FULL-WAITS = s_waitcnt vmcnt(0) count when the loop holds >= 4 loads and >= 2 of them")
+    print("# s_waitcnt vmcnt(0), FULL-WAITS = s_waitcnt vmcnt(0) count when the loop holds >= 4 loads and >= 2 of them;")
+    print("# `steady-state iteration` (MFMA loops): the cheapest cycle header -> header through every MFMA-issuing block of the loop = what one")
+    print("# iteration executes when no once-per-tile branch (epilogue, tile change) is taken")
     for f in files:
         print(f"\n## {os.path.basename(f)}")
-        for name, md, waves, nops, tot, loops, ndiv in audit(f):
+        for name, md, waves, nops, tot, loops, ndiv, steady in audit(f):
             short = re.sub(r"\(.*", "", name)[:86]
             print(f"{short:86s} v{md['vgpr']:3d}(a{md['agpr']:<3d}) s{md['sgpr']:3d} spill {md['vspill']}/{md['sspill']} scratch {md['scratch']:4d} "
                   f"lds {md['lds']:6d} waves/SIMD {waves} instr {nops:5d}" + (f" IEEE-div {ndiv}" if ndiv else ""))
@@ -133,6 +230,9 @@ def main():
                 if n_ >= 24:
                     print("    loop %4d: " % n_ + " ".join(f"{k} {mix[k]}" for k in ("mfma", "lds", "vmem", "valu", "salu", "wait", "barrier") if k in mix)
                           + (f"  dep {dep}" if dep else "") + (f"  FULL-WAITS {full} for {loads} loads" if (full >= 2 and loads >= 4) else ""))
+            for n_, mix, full in steady:
+                print("    steady-state iteration %4d: " % n_ + " ".join(f"{k} {mix[k]}" for k in ("mfma", "lds", "vmem", "valu", "salu", "wait", "barrier") if k in mix)
+                      + f"  ({mix.get('valu', 0) / max(mix.get('mfma', 1), 1):.2f} VALU per MFMA, {full} x vmcnt(0))")
 
 
 if __name__ == "__main__":

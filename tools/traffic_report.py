@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""The train step's ALGORITHMIC HBM bytes per kernel family at BASELINE.json configs[2] (B = 64 @ 640x640, bf16), from the plan
+(Engine.algorithmic_bytes: every operand of every launch moved once; no GPU involved -- the plan is built at B = 2 on the CPU
+executor's library and rescaled, activation bytes being proportional to the batch), next to the PMC-measured traffic of the last
+committed profiles/r*_pmc_bench.json, and the forward BatchNorm passes a consumer-side fusion could drop.
+usage: python tools/traffic_report.py > profiles/rNN_step_bytes.txt"""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("Y5M_BWD_PW_MIN_M", str(200000 * 2 // 64))
+import torch  # noqa: E402
+from emu.harness import emulated  # noqa: E402
+from yolov5m_amd import config  # noqa: E402
+from yolov5m_amd.model import YOLOV5m  # noqa: E402
+from yolov5m_amd.ultralytics_loss import ComputeLoss  # noqa: E402
+from yolov5m_amd.utils.training_utils import NativeTrainStep  # noqa: E402
+
+# PMC kernel name -> launch-list kinds it serves
+PMC = {"bn_act_kernel": ["apply_fused", "apply"], "bn_bwd_reduce_kernel + bn_bwd_apply_kernel": ["bn_bwd(reduce + apply)", "bn_reduce"],
+       "conv_pw_kernel + conv_igemm_kernel + conv_igemm_multi_kernel + conv_gemm8_kernel + conv_halo_kernel": ["conv_igemm"],
+       "wgrad_kernel + wgrad_rows_kernel + unpack_wgrad_kernel": ["wgrad", "unpack"], "bwd_pw_kernel": ["bwd_pw"], "bwd_stem_kernel": ["bwd_stem"],
+       "adam_kernel + sumsq_kernel": ["optimizer"], "pack_batched_kernel": ["pack_weights"], "s2d_input_kernel": ["input"],
+       "upsample2x_kernel + upsample2x_bwd_kernel": ["upsample"],
+       "sppf_colmax_kernel + sppf_rowmax_kernel + maxpool5_gather_kernel + maxpool5_argmax_kernel": ["pool"]}
+
+with emulated():
+    B = 2
+    m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+    m.compute_dtype = "bf16"
+    m.train()
+    m.flatten_parameters()
+    st = NativeTrainStep(m, ComputeLoss(m), nt_max=8 * B)
+    eng = m._engine_for(torch.empty((B, 3, 640, 640), device="meta"))
+    r = st.algorithmic_bytes(eng, B=64)
+    print(f"# tools/traffic_report.py: algorithmic HBM bytes of one train step, B = 64 @ 640x640, bf16 (plan built at B = {B}, rescaled)")
+    print(f"total {r['total_bytes'] / 1e9:.3f} GB = activations {r['activation_bytes'] / 1e9:.3f} + parameters / gradients / workspaces {r['parameter_bytes'] / 1e9:.3f}")
+    print("lists: " + ", ".join(f"{k} {v / 1e9:.3f}" for k, v in r["lists"].items()))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench.json")))
+    pmc, steps = ({}, 1)
+    if files:
+        d = json.load(open(files[-1]))
+        pmc = d["kernels"]
+        steps = pmc.get("adam_kernel", {}).get("launches", 1)
+        print(f"measured column: {os.path.relpath(files[-1], ROOT)} ({steps} eager steps; plan-construction fills excluded)")
+    print(f"\n{'launch-list kind':28s} {'launches':>8s} {'algorithmic GB':>15s}")
+    for k, (b, n) in sorted(r["by_kind"].items(), key=lambda kv: -kv[1][0]):
+        print(f"{k:28s} {n:8d} {b / 1e9:15.3f}")
+    if pmc:
+        print(f"\n{'kernels (PMC)':100s} {'measured GB/step':>17s} {'algorithmic':>12s} {'ratio':>6s}")
+        tm = ta = 0.0
+        for names, kinds in PMC.items():
+            meas = sum(pmc[n]["hbm_bytes_per_launch"] * pmc[n]["launches"] for n in names.split(" + ") if n in pmc) / steps / 1e9
+            alg = sum(r["by_kind"].get(k, [0, 0])[0] for k in kinds) / 1e9
+            tm += meas
+            ta += alg
+            print(f"{names:100s} {meas:17.3f} {alg:12.3f} {meas / max(alg, 1e-9):6.2f}")
+        print(f"{'sum of the rows above':100s} {tm:17.3f} {ta:12.3f} {tm / ta:6.2f}")
+    # forward BatchNorm + SiLU passes (read y, write z: 4 B per element) whose output is read ONLY by 1x1 convolutions (+ their weight
+    # gradients): the passes a consumer-side "normalise in the loader" fusion could drop -- each needs the loader change in every
+    # kernel that reads the tensor (conv_pw / conv_gemm8 forward, wgrad_kernel or bwd_pw_kernel backward)
+    by_z = {}
+    for lay in eng.layers:
+        by_z.setdefault(id(lay.z.buf), []).append(lay)
+    cons = {}
+    for lay in eng.layers + eng.heads:
+        x = lay.x
+        root = x.parent if x.parent is not None else x
+        cons.setdefault(id(root.buf), []).append(lay)
+    drop = tot = 0
+    rows = []
+    for lay in eng.layers:
+        nb = lay.M * lay.cout * 2 * 2 * 64 // B
+        tot += nb
+        users = [c for c in cons.get(id(lay.z.buf), []) if c is not lay]
+        # consumers of the (possibly wider, concatenated) buffer this layer writes into
+        ok = bool(users) and all(getattr(c, "kk", 1) == 1 and getattr(c, "ss", 1) == 1 for c in users) and lay.res is None
+        # residual users (a later bottleneck adds this tensor) and pool / upsample readers are not 1x1 convolutions
+        if ok:
+            rows.append((lay.name, nb, [c.name for c in users]))
+            drop += nb
+    print(f"\nforward BatchNorm + SiLU passes: {tot / 1e9:.3f} GB per step; output read only by 1x1 convolutions (upper bound of a loader fusion, "
+          f"residual / pool / upsample readers not checked): {drop / 1e9:.3f} GB = {100.0 * drop / r['total_bytes']:.1f} % of the step")
+    for name, nb, users in rows:
+        print(f"  {name:28s} {nb / 1e9:6.3f} GB  -> {', '.join(users)}")
