@@ -10,6 +10,9 @@ import sys
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.environ.get("Y5M_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")),
+                                reason="host clang of the ROCm image not present (tests/emu compiles the kernel sources for its CPU executor with it)")
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 

@@ -16,6 +16,9 @@ import pytest
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.environ.get("Y5M_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")),
+                                reason="host clang of the ROCm image not present (tests/emu compiles the kernel sources for its CPU executor with it)")
 sys.path.insert(0, HERE)
 
 

@@ -625,6 +625,12 @@ def test_bf16_train_step_vs_quantisation_aware_oracle(golden):
     # test_bf16_per_layer_backward_on_engine_operands (2e-2 per tensor, layer-local, not chaotic).
     assert abs(gh - res[False][2]) <= 0.12 * res[False][2], (gh, res[True][2], res[False][2])
     assert abs(gh - res[True][2]) <= 0.15 * res[True][2], (gh, res[True][2], res[False][2])
+    # (the bounds above were re-based with no new hardware data. The round-2/3 bound -- 8 % against the quantised oracle --
+    #  stays as a WARNING, so that a GPU run shows where the norm lands relative to it until a soak has recorded the distribution)
+    if abs(gh - res[True][2]) > 0.08 * res[True][2]:
+        import warnings
+        warnings.warn(f"bf16 gradient norm {gh:.2f} is outside the round-3 bound (8 % of the quantised oracle's {res[True][2]:.2f}); "
+                      f"f32 oracle {res[False][2]:.2f}")
 
 
 @pytest.mark.parametrize("dtype,rtol", [("f32", 1e-4), ("bf16", 3e-3)])

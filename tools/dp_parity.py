@@ -115,6 +115,8 @@ rel = np.linalg.norm(d1 - d2) / np.linalg.norm(d2)
 #  of 2e-7, profiles/r04_adam_noise_emu.txt; only a gross error -- a bucket exchanged before its gradients were final in every step --
 #  reaches this bound)
 check("overlapped_vs_plain_update_after_4_adam_steps(informational)", rel, 2e-1)
+if rel > 5e-2:      # (the round-3 bound: kept as a WARN line -- tools/dp_soak.sh collects them -- until a GPU soak has recorded the distribution)
+    print(f"WARN rank{rank} overlapped_vs_plain_update_after_4_adam_steps {rel:.3e} exceeds the round-3 bound 5e-2", flush=True)
 
 # ---- 4. replayed steps of both schedules from identical parameters, lr = 0 ---------------------------------------------
 m2.flat_params.copy_(m.flat_params)

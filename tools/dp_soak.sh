@@ -12,6 +12,6 @@ for i in $(seq 1 "$N"); do
       tools/dp_parity.py > "$OUT/run_$i.log" 2>&1
   rc=$?
   if [ $rc -ne 0 ]; then fails=$((fails + 1)); echo "run $i rc $rc" >> "$OUT/summary.txt"; fi
-  grep -h "^CHECK\|FAILED\|dp parity ok" "$OUT/run_$i.log" | sed "s/^/run $i: /" >> "$OUT/summary.txt"
+  grep -h "^CHECK\|^WARN\|FAILED\|dp parity ok" "$OUT/run_$i.log" | sed "s/^/run $i: /" >> "$OUT/summary.txt"
 done
 echo "soak: $N runs, $fails failed ($*)" | tee -a "$OUT/summary.txt"

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round 5 -- everything that waits for a GPU, ONE gpurun call, in the order it matters (a short lease still yields GPUTEST + BENCH):
+#   /usr/local/graft/bin/gpurun --timeout 9000 -- 'bash tools/r5_gpu_job.sh'
+# (rounds 4 and 5 never got a box: every call was refused -- "GPU use for this repository has been closed from outside the build")
+# Blocks 1-3 ~25 min, 4 ~25 min, 5-6 ~30 min, 7-8 ~20 min. A shorter --timeout cuts the tail.
+O=gpurun_out/r5; mkdir -p $O
+# 1. HEAD's GPU suite once WITHOUT -x (every failure listed), smoke, the bench line with all its legs
+python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 > $O/suite_1.txt; tail -1 $O/suite_1.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.txt
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo; tail -3 $O/bench.err
+# 2. the round's rocprof evidence set (kernel stats, HBM PMC, conv PMC inside the step, per-layer table) -> copy to profiles/r05_*
+bash tools/profile_round.sh > $O/prof_round.log 2>&1; tail -12 $O/prof_round.log
+# 3. suite twice more (three consecutive greens with the commit hash)
+for i in 2 3; do python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/suite_$i.txt; tail -1 $O/suite_$i.txt; done
+# 4. A/B inside the step, one bit at a time: the five round-4 kernel forms (Y5M_R4_KERNELS) -- op tests with all five on first --
+#    and the round-5 256 x 96 conv tile (Y5M_CONV_T256). Decision rule: what is not faster INSIDE THE STEP stays off.
+bash tools/ab_r4_kernels.sh 3 > $O/ab_r4_kernels.log 2>&1; cat gpurun_out/ab_r4_kernels/r4_forms_op_tests.txt gpurun_out/ab_r4_kernels/step.txt
+bash tools/ab_step.sh 3 "default|" "t256_single|Y5M_CONV_T256=1" "t256_double|Y5M_CONV_T256=2" 2>&1 | tail -9 | tee $O/ab_t256.txt
+for m in 0 1 2; do echo "== 96 -> 96 3x3 @ 80x80 alone: Y5M_CONV_T256=$m" | tee -a $O/t256_alone.txt
+  Y5M_CONV_T256=$m python tools/conv_bench.py fwd 64 96 80 80 96 3 1 30 2>/dev/null | tee -a $O/t256_alone.txt
+  Y5M_CONV_T256=$m python tools/conv_bench.py dgrad 64 96 80 80 96 3 1 30 2>/dev/null | tee -a $O/t256_alone.txt; done
+# 5. dp_parity soak: which bound fires, and the distribution of every checked value (20 standalone runs)
+bash tools/dp_soak.sh 20 $O/dp_soak > $O/dp_soak.txt 2>&1; tail -1 $O/dp_soak.txt
+# 6. the graph-destroy hunt (stand-alone HIP reproducer + the known reproducer under the heap checker)
+bash tools/graph_hunt_r4.sh > $O/graph_hunt.log 2>&1; cat gpurun_out/graph_hunt_r4/summary.txt
+# 7. attribution of the bf16 first-step loss shift (IEEE division / accurate expf builds)
+bash tools/loss_shift_ab.sh > $O/loss_shift.log 2>&1; cat gpurun_out/loss_shift/summary.txt
+# 8. two-rank bench line on this box's one GPU (gloo; the RCCL path itself needs two devices: the driver's SCALE run)
+Y5M_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-roofline --no-cpu-baseline > $O/bench_2ranks_gloo.json 2> $O/bench_2ranks_gloo.err; head -c 300 $O/bench_2ranks_gloo.json; echo

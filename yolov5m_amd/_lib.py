@@ -234,8 +234,31 @@ def check(rc, what):
         raise Y5MError(f"{what} failed (rc={rc}): {lib().y5m_last_error().decode()}")
 
 
+class _DeviceGuard:
+    """The ONE seam between this package and the device: which stream launches go to, where the wrappers create their own tensors,
+    and what they refuse. The product has exactly this implementation -- "cuda", host tensors refused, no CPU fallback
+    (tests/test_abi.py::test_no_cpu_fallback). TEST-ONLY hook: tests/emu/harness.py replaces `_device_guard` (together with the
+    library handle `_lib`) inside a scoped mock.patch to drive the kernel sources compiled for its CPU executor; nothing else may."""
+    device = "cuda"
+
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def tensors(self, *tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise Y5MError("yolov5m_amd ops run on the MI355X only: got a CPU tensor (no CPU fallback).")
+
+    def module_device(self, dev):
+        if torch.device(dev).type != "cuda":
+            raise Y5MError("YOLOV5m runs on the MI355X only: call .to('cuda') first (no CPU fallback)")
+
+
+_device_guard = _DeviceGuard()
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _device_guard.stream()
 
 
 def ptr(t):
@@ -246,17 +269,16 @@ def ptr(t):
 
 
 def require_cuda(*tensors):
-    for t in tensors:
-        if t is not None and not t.is_cuda:
-            raise Y5MError("yolov5m_amd ops run on the MI355X only: got a CPU tensor (no CPU fallback).")
+    _device_guard.tensors(*tensors)
 
 
-DEVICE = "cuda"         # where the wrappers create their own tensors (there is no other choice: no CPU fallback)
+def device():
+    """where the wrappers create their own tensors (there is no other choice: no CPU fallback)"""
+    return _device_guard.device
 
 
 def require_cuda_device(dev):
-    if torch.device(dev).type != "cuda":
-        raise Y5MError("YOLOV5m runs on the MI355X only: call .to('cuda') first (no CPU fallback)")
+    _device_guard.module_device(dev)
 
 
 def int_array(vals):

@@ -99,7 +99,7 @@ def non_max_suppression_aladdin(bboxes, iou_threshold, threshold, box_format="co
     if not bboxes:
         return []
     L = _lib.lib()
-    t = torch.tensor(bboxes, dtype=torch.float32, device=_lib.DEVICE).reshape(1, -1, 6).contiguous()
+    t = torch.tensor(bboxes, dtype=torch.float32, device=_lib.device()).reshape(1, -1, 6).contiguous()
     N = t.shape[1]
     rows = torch.empty((1, max_detections, 6), dtype=torch.float32, device=t.device)
     idx = torch.empty((1, max_detections), dtype=torch.int32, device=t.device)
@@ -119,7 +119,7 @@ def non_max_suppression(batch_bboxes, iou_threshold, threshold, max_detections=3
     tolist=False -> ONE concatenated tensor for the whole batch (image boundaries lost, as in the
     reference :209)."""
     if not torch.is_tensor(batch_bboxes):
-        batch_bboxes = torch.as_tensor(batch_bboxes, dtype=torch.float32, device=_lib.DEVICE)
+        batch_bboxes = torch.as_tensor(batch_bboxes, dtype=torch.float32, device=_lib.device())
     rows, _, cnt = nms_batched(batch_bboxes, iou_threshold, threshold, max_detections)
     counts = cnt.tolist()        # the only host sync of the detect path
     per_img = [rows[b, :c] for b, c in enumerate(counts)]

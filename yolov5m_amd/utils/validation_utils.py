@@ -31,7 +31,7 @@ class DenseTargets:
         from .. import _lib
         self._np, self._lib = np, _lib
         self.S = [int(v) for v in S]
-        dev = device or _lib.DEVICE
+        dev = device or _lib.device()
         a = torch.as_tensor(anchors, dtype=torch.float32)
         if strided:
             a = a.reshape(3, 3, 2).clone()
