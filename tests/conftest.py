@@ -26,3 +26,21 @@ def golden():
         return cache[name]
 
     return load
+
+
+# GPU tests that have not yet passed on hardware (written while the GPU pool was closed to this repository, rounds 4-5; green on the
+# CPU executor of tests/emu) are collected LAST, in front of the two-rank test only: the driver's `pytest -m gpu -x` then reports the
+# long-proven cases before it can stop at one of these. Remove a name once a hardware run has passed it.
+_NOT_YET_ON_HARDWARE = {
+    "test_accumulation_path_sees_a_changed_learning_rate", "test_bf16_per_layer_backward_full_size_default_dispatch",
+    "test_submodule_backward_matches_torch", "test_class_obj_accuracy_counts_bit_exact",
+    "test_dense_targets_builder_matches_dataset_algorithm",
+}
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(it):
+        if "test_gpu_zz_dp" in it.nodeid:
+            return 2
+        return 1 if getattr(it, "originalname", it.name) in _NOT_YET_ON_HARDWARE else 0
+    items.sort(key=rank)          # (stable: everything else keeps its order)

@@ -131,7 +131,7 @@ def test_bench_untimed_legs_execute_on_the_executor():
     assert g == {"error": "broken leg failed: ZeroDivisionError: division by zero"}
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1"])      # ("2", the double-buffered form: tests/emu/knob_variants.py and the staged GPU A/B)
 def test_t256_conv_tile_green_on_the_executor(mode):
     """Y5M_CONV_T256 (default 0; csrc/y5m_conv.hip): the 96-channel layers on a 256 x 96 tile with 64 x 96 wave tiles, single (1)
     or double (2) LDS buffer -- built in round 5 without a GPU, so its parity evidence is this: the op-level conv cases (forward,
