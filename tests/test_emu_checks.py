@@ -129,24 +129,3 @@ def test_bench_untimed_legs_execute_on_the_executor():
     import bench
     g = bench._guarded("broken", lambda: 1 / 0)
     assert g == {"error": "broken leg failed: ZeroDivisionError: division by zero"}
-
-
-@pytest.mark.parametrize("mode", ["1"])      # ("2", the double-buffered form: tests/emu/knob_variants.py and the staged GPU A/B)
-def test_t256_conv_tile_green_on_the_executor(mode):
-    """Y5M_CONV_T256 (default 0; csrc/y5m_conv.hip): the 96-channel layers on a 256 x 96 tile with 64 x 96 wave tiles, single (1)
-    or double (2) LDS buffer -- built in round 5 without a GPU, so its parity evidence is this: the op-level conv cases (forward,
-    statistics and fused epilogues, data gradients incl. the stride-2 parity classes in one launch) with the knob on, and the
-    dispatch really choosing the new instantiation for the 96 -> 96 3x3 layer."""
-    e = dict(os.environ, Y5M_CONV_T256=mode, Y5M_EMU_THREADS="4")
-    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "run_gpu_tests.py"), "test_gpu_conv",
-                        "--only=test_conv_forward|conv_fused_epilogue|conv_stats_epilogue|halo_forward|test_conv_dgrad|conv_multi|conv_bn_accumulator"],
-                       env=e, capture_output=True, text=True, timeout=1500)
-    lines = [l for l in r.stdout.splitlines() if " test_" in l]
-    assert r.returncode == 0 and len(lines) >= 30, (r.returncode, r.stderr[-800:])
-    bad = [l for l in lines if not l.endswith(" ok")]
-    assert not bad, bad[:3]
-    c = _child('import test_dispatch_cpu as D\n    from yolov5m_amd._lib import EPI_DGRAD, EPI_RAW_STATS\n'
-               '    want = "conv_igemm_kernel<bf16,4,1,4,6,%d>"\n' % (int(mode) - 1) +
-               '    assert D._conv_name(64, 96, 80, 80, 96, 3, 1, EPI_RAW_STATS) == want, D._conv_name(64, 96, 80, 80, 96, 3, 1, EPI_RAW_STATS)\n'
-               '    assert D._conv_name(64, 96, 80, 80, 96, 3, 1, EPI_DGRAD) == want', Y5M_CONV_T256=mode)
-    assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-800:]

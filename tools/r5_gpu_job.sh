@@ -12,13 +12,9 @@ python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; head -c 4
 bash tools/profile_round.sh > $O/prof_round.log 2>&1; tail -12 $O/prof_round.log
 # 3. suite twice more (three consecutive greens with the commit hash)
 for i in 2 3; do python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/suite_$i.txt; tail -1 $O/suite_$i.txt; done
-# 4. A/B inside the step, one bit at a time: the five round-4 kernel forms (Y5M_R4_KERNELS) -- op tests with all five on first --
-#    and the round-5 256 x 96 conv tile (Y5M_CONV_T256). Decision rule: what is not faster INSIDE THE STEP stays off.
+# 4. A/B inside the step, one bit at a time: the five round-4 kernel forms (Y5M_R4_KERNELS) -- op tests with all five on first.
+#    Decision rule: what is not faster INSIDE THE STEP stays off.
 bash tools/ab_r4_kernels.sh 3 > $O/ab_r4_kernels.log 2>&1; cat gpurun_out/ab_r4_kernels/r4_forms_op_tests.txt gpurun_out/ab_r4_kernels/step.txt
-bash tools/ab_step.sh 3 "default|" "t256_single|Y5M_CONV_T256=1" "t256_double|Y5M_CONV_T256=2" 2>&1 | tail -9 | tee $O/ab_t256.txt
-for m in 0 1 2; do echo "== 96 -> 96 3x3 @ 80x80 alone: Y5M_CONV_T256=$m" | tee -a $O/t256_alone.txt
-  Y5M_CONV_T256=$m python tools/conv_bench.py fwd 64 96 80 80 96 3 1 30 2>/dev/null | tee -a $O/t256_alone.txt
-  Y5M_CONV_T256=$m python tools/conv_bench.py dgrad 64 96 80 80 96 3 1 30 2>/dev/null | tee -a $O/t256_alone.txt; done
 # 5. dp_parity soak: which bound fires, and the distribution of every checked value (20 standalone runs)
 bash tools/dp_soak.sh 20 $O/dp_soak > $O/dp_soak.txt 2>&1; tail -1 $O/dp_soak.txt
 # 6. the graph-destroy hunt (stand-alone HIP reproducer + the known reproducer under the heap checker)

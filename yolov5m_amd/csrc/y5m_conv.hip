@@ -356,11 +356,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvParams& P, const int l
     }
 }
 
-// (the 256 x 96 tile's 64 x 96 wave tiles hold 96 accumulator registers: two workgroups per CU are asked for explicitly -- left alone
-//  the compiler takes 308 registers and one wave per SIMD)
 template <typename T, int WM, int WN, int MF, int NF, bool DB>
-__global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM == 4 && WN == 1 && MF == 4 && NF == 6) ? 2 : 1)
-void conv_igemm_kernel(const ConvParams P) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams P) {
     conv_igemm_body<T, WM, WN, MF, NF, DB>(P, xcd_logical_id(blockIdx.x, gridDim.x));
 }
 
@@ -371,8 +368,7 @@ void conv_igemm_kernel(const ConvParams P) {
 struct ConvMulti { ConvParams p[4]; int n; };        // p MUST stay the first member (see conv_igemm_multi_kernel)
 static_assert(offsetof(ConvMulti, p) == 0, "kernarg layout");
 template <typename T, int WM, int WN, int MF, int NF>
-__global__ __launch_bounds__(WM * WN * 64, (sizeof(T) == 2 && WM == 4 && WN == 1 && MF == 4 && NF == 6) ? 2 : 1)
-void conv_igemm_multi_kernel(const ConvMulti MP) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_multi_kernel(const ConvMulti MP) {
     const int lid = xcd_logical_id(blockIdx.x, gridDim.x);
     const int cls = lid % MP.n;
     // the class's parameter block straight from the kernarg segment (MP is its first and only explicit argument): a
@@ -433,14 +429,6 @@ static int launch_conv_db(ConvParams& P, hipStream_t st) {
 static int g_bn192 = -1;
 static int g_w8 = -1;      // Y5M_CONV_W8: 8-wave workgroups (0 off, 1 the 192-channel tile, 2 also the 96-channel tile)
 static int g_sbuf_kt = -1;   // K steps up to which the single-buffer variant is used (Y5M_CONV_SBUF_KT, default: always)
-// Y5M_CONV_T256 (round 5, default 0: built without a GPU, A/B staged in tools/ab_step.sh): the 96-channel tile as 256 pixels x 96
-// channels, four waves of 64 x 96 (wave tiles side by side on the PIXEL axis, every wave reads all 96 weight rows). Why: the
-// tiled kernel is bound by its LDS pipe, not by its schedule -- per 64-deep K step the 128 x 96 tile (waves of 64 x 48) stages
-// 28 KB through ds_write_b128 (13 cycles per 1 KB wave-instruction: 364 cycles) and reads 4 x 14 KB of fragments (219 cycles)
-// for 384 matrix-pipe cycles per SIMD: LDS / MFMA = 1.52. 256 x 96 with 64 x 96 wave tiles: 572 + 312 cycles for 768: 1.15 --
-// 3.3 fragment rows per MFMA instead of 4.7 and the weight rows staged once per 256 pixels instead of once per 128. 48 MFMAs per
-// K step and wave. 1 = single LDS buffer (44 KB, two workgroups per CU by registers), 2 = two buffers (one barrier per K step).
-static int g_t256 = -1;
 template <typename T, int WM, int WN, int MF, int NF>
 static int launch_conv(ConvParams& P, hipStream_t st) {
     // measured with the 8-wave tile: the single-buffer variant (half the LDS, more resident workgroups) wins for
@@ -506,9 +494,6 @@ static int conv_dispatch(ConvParams& P, int dtype, hipStream_t st) {
             return launch_conv<bf16_t, 2, 2, 4, 6>(P, st);
         }
         if (g_w8 < 0) { const char* e = getenv("Y5M_CONV_W8"); g_w8 = e ? atoi(e) : 1; }
-        if (g_t256 < 0) { const char* e = getenv("Y5M_CONV_T256"); g_t256 = e ? atoi(e) : 0; }
-        if (g_t256 == 1) return launch_conv_db<bf16_t, 4, 1, 4, 6, false>(P, st);      // 256x96 tile, 4 waves of 64x96
-        if (g_t256 >= 2) return launch_conv_db<bf16_t, 4, 1, 4, 6, true>(P, st);
         if (g_w8 >= 2) return launch_conv<bf16_t, 4, 2, 2, 3>(P, st);      // 128x96 tile, 8 waves of 32x48
         return launch_conv<bf16_t, 2, 2, 4, 3>(P, st);
     } else {
@@ -600,7 +585,5 @@ extern "C" int y5m_conv_multi(const y5m_conv_args* args, int n, int dtype, void*
     const int BN = y5m_conv_tile_n(args[0].N);
     if (BN == 48) return launch_conv_multi<bf16_t, 4, 1, 2, 3>(MP, st);
     if (BN == 192) return launch_conv_multi<bf16_t, 2, 4, 4, 3>(MP, st);
-    if (g_t256 < 0) { const char* e = getenv("Y5M_CONV_T256"); g_t256 = e ? atoi(e) : 0; }
-    if (g_t256) return launch_conv_multi<bf16_t, 4, 1, 4, 6>(MP, st);
     return launch_conv_multi<bf16_t, 2, 2, 4, 3>(MP, st);
 }
