@@ -395,6 +395,16 @@ int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, v
 size_t y5m_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C);
 int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, int B, int H, int W, int C, void* gin,
                      int ldgin, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* the whole backward cascade of the SPPF pools (model.py:108-110; autograd of the three MaxPool2d(5,1,2)): with z0 = x,
+ * z1 = pool(z0), z2 = pool(z1) and g0..g3 the gradients of the four concat slices: g2 += bwd(z2; g3), g1 += bwd(z1; g2),
+ * g0 += bwd(z0; g1). One launch where the LDS-tiled form applies (y5m_sppf_pool_tiled), else three y5m_maxpool5_bwd calls;
+ * ws as for y5m_maxpool5_bwd. */
+int y5m_sppf_pool_bwd(const void* z0, const void* z1, const void* z2, int ldz, void* g0, void* g1, void* g2,
+                      const void* g3, int ldg, int B, int H, int W, int C, void* ws, size_t ws_bytes, int dtype,
+                      void* stream);
+/* 1 when y5m_sppf_pool / y5m_sppf_pool_bwd run their LDS-tiled forms for this shape (Y5M_POOL_TILE and an image x one
+ * 8-channel piece fits the LDS budget) */
+int y5m_sppf_pool_tiled(int H, int W, int C, int dtype);
 /* d(loss)/d(logits) (B,naxs,ny,nx,nch) f32 -> head conv output gradient [B*ny*nx][ldp] + bias grad */
 int y5m_head_grad_pack(const float* dlogits, int B, int naxs, int ny, int nx, int nch, void* dyp, int ldp,
                        float* dbias, int dtype, void* stream);

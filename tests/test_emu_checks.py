@@ -129,3 +129,24 @@ def test_bench_untimed_legs_execute_on_the_executor():
     import bench
     g = bench._guarded("broken", lambda: 1 / 0)
     assert g == {"error": "broken leg failed: ZeroDivisionError: division by zero"}
+
+
+def test_pool_tiled_forms_bit_identical_on_the_executor(tmp_path):
+    """Y5M_POOL_TILE=1 (default 0, csrc/y5m_nn.hip: one image x a slab of channels per workgroup in LDS; the backward cascade of the
+    three SPPF pools as ONE launch): the f32 forms against ATen bit-exactly and the bf16 forms bit-identical to the separable
+    kernels -- tests/test_gpu_model.py::test_sppf_pool_tiled_forms_subprocess does this on the GPU, this is its executor twin."""
+    import numpy as np
+    outs = {}
+    for tag, env in (("sep", {}), ("tiled", {"Y5M_POOL_TILE": "1"})):
+        body = ("import test_gpu_model as M\n    M.DEV = 'cpu'\n    from yolov5m_amd import _lib\n"
+                f"    assert _lib.lib().y5m_sppf_pool_tiled(20, 20, 384, _lib.BF16) == {int(tag == 'tiled')}\n"
+                f"    assert _lib.lib().y5m_sppf_pool_tiled(40, 40, 384, _lib.BF16) == {int(tag == 'tiled')}\n"
+                "    for s in ((4, 96, 10, 13), (2, 384, 20, 20), (1, 64, 40, 40)):\n        M.test_sppf_pool_forward_backward_bit_exact(s)\n"
+                "    for i, s in enumerate(((2, 384, 20, 20), (1, 64, 40, 40), (3, 40, 7, 9))):\n"
+                f"        a, b = M._pool_bf16_run(*s); np.savez({str(tmp_path / tag)!r} + str(i), a=a, b=b)")
+        c = _child(body, **env)
+        assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-1500:]
+        outs[tag] = [np.load(str(tmp_path / f"{tag}{i}.npz")) for i in range(3)]
+    for s, t in zip(outs["sep"], outs["tiled"]):
+        assert np.array_equal(s["a"], t["a"]) and np.array_equal(s["b"], t["b"])
+        assert np.abs(s["b"]).max() > 0

@@ -249,16 +249,19 @@ def test_full_gradients_b16_320_fp64_calibrated(golden):
     print("worst sampled-gradient error, (hip, ref_f32, tensor):", worst)
 
 
-def test_sppf_pool_forward_backward_bit_exact():
-    """y5m_sppf_pool (three cascaded MaxPool2d(5,1,2), reference model.py:103-112) and y5m_maxpool5_bwd against ATen's
-    max_pool2d and its autograd, BIT-EXACT, on data with no ties, on SiLU-shaped data and on quantised data full of exact
-    ties (argmax = first maximum in row-major window order). The gradient buffers live inside a 4-slice concat buffer as
-    in the engine (accumulation into slices, ld = 4C)."""
+@pytest.mark.parametrize("shape", [(4, 96, 10, 13), (2, 384, 20, 20), (1, 64, 40, 40)])
+def test_sppf_pool_forward_backward_bit_exact(shape):
+    """y5m_sppf_pool (three cascaded MaxPool2d(5,1,2), reference model.py:103-112) and its backward cascade (y5m_sppf_pool_bwd =
+    three y5m_maxpool5_bwd) against ATen's max_pool2d and its autograd, BIT-EXACT, on data with no ties, on SiLU-shaped data and on
+    quantised data full of exact ties (argmax = first maximum in row-major window order). The gradient buffers live inside a
+    4-slice concat buffer as in the engine (accumulation into slices, ld = 4C). Shapes: a ragged one, the 20x20 SPPF stage of the
+    640^2 model, the 40x40 one of 1280^2. (Y5M_POOL_TILE=1 runs the LDS-tiled forms through the same entry points:
+    test_sppf_pool_tiled_forms_subprocess.)"""
     import torch.nn.functional as F
     from yolov5m_amd import _lib
     from yolov5m_amd._lib import F32
     L, st = _lib.lib(), _lib.stream_ptr
-    B, C, H, W = 4, 96, 10, 13
+    B, C, H, W = shape
     gen = torch.Generator().manual_seed(7)
     for kind in ("randn", "silu", "quantised"):
         x = torch.randn((B, C, H, W), generator=gen)
@@ -283,11 +286,59 @@ def test_sppf_pool_forward_backward_bit_exact():
         for i, p in enumerate((p1, p2, p3)):
             assert torch.equal(cat[..., (i + 1) * C:(i + 2) * C].cpu(), p.detach().permute(0, 2, 3, 1)), (kind, i)
         pws = torch.zeros(L.y5m_maxpool5_bwd_workspace_bytes(B, H, W, C), dtype=torch.uint8, device=DEV)
-        for lvl in (2, 1, 0):            # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)
-            _lib.check(L.y5m_maxpool5_bwd(sl[lvl], 4 * C, gp[lvl + 1], 4 * C, B, H, W, C, gp[lvl], 4 * C, 1, _lib.ptr(pws),
-                                          pws.numel(), F32, st()), "maxpool5_bwd")
+        # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)
+        _lib.check(L.y5m_sppf_pool_bwd(sl[0], sl[1], sl[2], 4 * C, gp[0], gp[1], gp[2], gp[3], 4 * C, B, H, W, C, _lib.ptr(pws),
+                                       pws.numel(), F32, st()), "sppf_pool_bwd")
         got = gc[..., :C].cpu().permute(0, 3, 1, 2)
         assert torch.equal(got, xr.grad), (kind, float((got - xr.grad).abs().max()))
+
+
+def _pool_bf16_run(B, C, H, W):
+    """the pool forward + backward cascade on bf16 tensors inside 4-slice concat buffers; returns every output as float32"""
+    from yolov5m_amd import _lib
+    from yolov5m_amd._lib import BF16
+    L, st = _lib.lib(), _lib.stream_ptr
+    gen = torch.Generator().manual_seed(11)
+    cat = torch.zeros(B, H, W, 4 * C, dtype=torch.bfloat16, device=DEV)
+    cat[..., :C] = ((torch.randn((B, H, W, C), generator=gen) * 4).round() / 4).to(torch.bfloat16).to(DEV)      # (ties included)
+    gc = torch.randn((B, H, W, 4 * C), generator=gen).to(torch.bfloat16).to(DEV)
+    ws = torch.zeros(L.y5m_sppf_pool_workspace_bytes(B, H, W, C), dtype=torch.uint8, device=DEV)
+    sl = [cat.data_ptr() + 2 * i * C for i in range(4)]
+    gp = [gc.data_ptr() + 2 * i * C for i in range(4)]
+    _lib.check(L.y5m_sppf_pool(sl[0], 4 * C, B, H, W, C, sl[1], sl[2], sl[3], _lib.ptr(ws), ws.numel(), BF16, st()), "pool")
+    pws = torch.zeros(L.y5m_maxpool5_bwd_workspace_bytes(B, H, W, C), dtype=torch.uint8, device=DEV)
+    _lib.check(L.y5m_sppf_pool_bwd(sl[0], sl[1], sl[2], 4 * C, gp[0], gp[1], gp[2], gp[3], 4 * C, B, H, W, C, _lib.ptr(pws),
+                                   pws.numel(), BF16, st()), "sppf_pool_bwd")
+    torch.cuda.synchronize()
+    return cat.float().cpu().numpy(), gc.float().cpu().numpy()
+
+
+def test_sppf_pool_tiled_forms_subprocess(tmp_path):
+    """Y5M_POOL_TILE=1 (default 0: written without a GPU): y5m_sppf_pool / y5m_sppf_pool_bwd as ONE LDS-tiled launch each. In a
+    child (the knob is read once): the f32 forms against ATen bit-exactly (the test above, all shapes), and the bf16 forms --
+    whose per-level results are rounded to bf16 between the levels -- bit-identical to the separable kernels of this process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("Y5M_POOL_TILE") == "1":
+        pytest.skip("already the child")
+    env = dict(os.environ, Y5M_POOL_TILE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "sppf_pool_forward_backward_bit_exact"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    child = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import test_gpu_model as T\nfrom yolov5m_amd import _lib\n"
+             "assert _lib.lib().y5m_sppf_pool_tiled(20, 20, 384, _lib.BF16) == 1\n"
+             "for i, s in enumerate(((2, 384, 20, 20), (1, 64, 40, 40), (3, 40, 7, 9))):\n"
+             "    a, b = T._pool_bf16_run(*s); np.savez(sys.argv[1] + str(i), a=a, b=b)\n") % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, "-c", child, str(tmp_path / "t")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from yolov5m_amd import _lib
+    assert _lib.lib().y5m_sppf_pool_tiled(20, 20, 384, _lib.BF16) == 0          # this process: the separable kernels
+    for i, s in enumerate(((2, 384, 20, 20), (1, 64, 40, 40), (3, 40, 7, 9))):
+        a, b = _pool_bf16_run(*s)
+        t = np.load(str(tmp_path / f"t{i}.npz"))
+        assert np.array_equal(t["a"], a) and np.array_equal(t["b"], b), s
 
 
 def _layer_nchw(t, ld, off, B, H, W, C):

@@ -177,6 +177,9 @@ _SIGS = {
     "y5m_sppf_pool_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "y5m_sppf_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_size_t, c_int, c_void_p]),
+    "y5m_sppf_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "y5m_sppf_pool_tiled": (c_int, [c_int, c_int, c_int, c_int]),
     "y5m_maxpool5_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "y5m_maxpool5_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                  c_int, c_void_p, c_size_t, c_int, c_void_p]),

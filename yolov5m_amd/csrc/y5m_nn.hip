@@ -1128,6 +1128,10 @@ __global__ void sppf_colmax_kernel(const T* __restrict__ h5, const T* __restrict
     const size_t o = (((size_t)b * H + yy) * W + xx) * ld + c;
     store8<T>(o1 + o, m5); store8<T>(o2 + o, m9); store8<T>(o3 + o, m13);
 }
+static int pool_tile_cs(int H, int W, int C, int dtype, int bytes_per_item_bf16, int bytes_per_item_f32);
+extern "C" int y5m_sppf_pool_tiled(int H, int W, int C, int dtype);
+template <typename T> __global__ void sppf_pool_tile_kernel(const T* __restrict__ x, int ld, int H, int W, int C8, int CS,
+                                                            T* __restrict__ o1, T* __restrict__ o2, T* __restrict__ o3);
 extern "C" size_t y5m_sppf_pool_workspace_bytes(int B, int H, int W, int C) { return (size_t)3 * B * H * W * C * 4 + 256; }
 extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, void* ws,
                              size_t ws_bytes, int dtype, void* stream) {
@@ -1136,6 +1140,18 @@ extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, 
     const int64_t n = (int64_t)B * H * W * (C / 8);
     const size_t plane = (size_t)B * H * W * C;
     hipStream_t st = y5m_stream(stream);
+    if (y5m_sppf_pool_tiled(H, W, C, dtype)) {         // Y5M_POOL_TILE: one image x CS pieces per workgroup, everything in LDS
+        const int cs = pool_tile_cs(H, W, C, dtype, 2 * 16, 2 * 32);
+        const int slabs = (C / 8 + cs - 1) / cs;
+        const size_t lds = (size_t)H * W * cs * (dtype == Y5M_BF16 ? 2 * 16 : 2 * 32);
+        DISPATCH_T(dtype, {
+            auto kern = sppf_pool_tile_kernel<T>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(B * slabs)), dim3(256), lds, st, (const T*)x, ld, H, W, C / 8, cs, (T*)o1, (T*)o2, (T*)o3);
+        })
+        Y5M_CHECK_LAUNCH("sppf_pool_tile_kernel");
+        return Y5M_OK;
+    }
     DISPATCH_T(dtype, T* h5 = (T*)ws; T* h9 = h5 + plane; T* h13 = h9 + plane;
                hipLaunchKernelGGL(sppf_rowmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)x, ld, B, H, W, C / 8, h5, h9, h13);
                hipLaunchKernelGGL(sppf_colmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)h5, (const T*)h9, (const T*)h13, B, H, W, C / 8, (T*)o1, (T*)o2, (T*)o3, ld);)
@@ -1232,6 +1248,223 @@ extern "C" int y5m_maxpool5_bwd(const void* z, int ldz, const void* g, int ldg, 
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool5_gather_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, code, (const T*)g,
                                          ldg, B, H, W, C / 8, (T*)gin, ldgin, accumulate);)
     Y5M_CHECK_LAUNCH("maxpool5_gather_kernel");
+    return Y5M_OK;
+}
+
+// =================================================================================================
+// LDS-tiled forms of the SPPF pooling (round 5; Y5M_POOL_TILE, default 0: written without a GPU, A/B staged).
+// Why: profiles/r05_step_bytes.txt -- the four pooling kernels move 1.55 GB per step for 0.32 GB of tensors (separable 13-tap
+// passes through workspaces, an argmax code plane, 25-tap gathers: 446 us per step in round 3's kernel statistics against ~80 us
+// of HBM time). A 20x20 (40x40 at 1280^2) image is small: one workgroup takes ONE IMAGE x a slab of CS 8-channel pieces into
+// LDS and does everything there --
+//   forward : x once in, the three cascaded 5x5 maxima (row pass / column pass, ping-pong between two LDS images) out: 4 tensor
+//             passes instead of 2 launches + 3 workspace planes;
+//   backward: the WHOLE cascade g2 += bwd(p2; g3), g1 += bwd(p1; g2), g0 += bwd(x; g1) in one launch: per level the pool input
+//             and the incoming gradient sit in LDS, the argmax codes are formed there, the gather reads them there; the updated
+//             gradient is stored (rounded to T exactly as the per-level launches store it) and kept in LDS as the next level's
+//             incoming gradient: 10 tensor passes instead of 6 launches, 12 passes and a code plane.
+// Same arithmetic in the same order as the kernels above (first maximum in row-major window order; gather sums in (dy, dx)
+// order): bit-identical results, tests/test_gpu_model.py::test_sppf_pool_tiled_forms_equal_the_separable_ones.
+// =================================================================================================
+__device__ __forceinline__ void raw_pack8(const float v[8], Raw8<bf16_t>& r) {      // exact for values that ARE bf16; else RNE
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.q[i] = f32x2_to_bf16x2(v[2 * i], v[2 * i + 1]);
+}
+__device__ __forceinline__ void raw_pack8(const float v[8], Raw8<float>& r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.a[i] = v[i]; r.b[i] = v[4 + i]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_tile_kernel(const T* __restrict__ x, int ld, int H, int W, int C8, int CS,
+                                                            T* __restrict__ o1, T* __restrict__ o2, T* __restrict__ o3) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int slabs = (C8 + CS - 1) / CS;
+    const int b = blockIdx.x / slabs, slab = blockIdx.x - b * slabs;
+    const int c80 = slab * CS, ncs = min(CS, C8 - c80);
+    const int n = H * W * ncs;                         // items: i = pixel * ncs + piece
+    Raw8<T>* A = reinterpret_cast<Raw8<T>*>(smem);
+    Raw8<T>* Bf = A + H * W * CS;
+    const size_t img = (size_t)b * H * W;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / ncs, cs = i - pix * ncs;
+        raw_load8(x + (img + pix) * ld + (c80 + cs) * 8, A[i]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        T* const o = lvl == 0 ? o1 : (lvl == 1 ? o2 : o3);
+        for (int i = threadIdx.x; i < n; i += 256) {   // row pass: A -> Bf
+            const int pix = i / ncs, cs = i - pix * ncs;
+            const int yy = pix / W, xx = pix - yy * W;
+            float m[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int x2 = xx + dx;
+                if (x2 < 0 || x2 >= W) continue;
+                float v[8];
+                raw_unpack8(A[(yy * W + x2) * ncs + cs], v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+            raw_pack8(m, Bf[i]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {   // column pass: Bf -> A (= the pool's output: stored, and the next level's input)
+            const int pix = i / ncs, cs = i - pix * ncs;
+            const int yy = pix / W, xx = pix - yy * W;
+            float m[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int y2 = yy + dy;
+                if (y2 < 0 || y2 >= H) continue;
+                float v[8];
+                raw_unpack8(Bf[(y2 * W + xx) * ncs + cs], v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+            raw_pack8(m, A[i]);
+            store8<T>(o + (img + pix) * ld + (c80 + cs) * 8, m);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_bwd_tile_kernel(const T* __restrict__ z0, const T* __restrict__ z1,
+                                                                const T* __restrict__ z2, int ldz, T* __restrict__ g0,
+                                                                T* __restrict__ g1, T* __restrict__ g2, const T* __restrict__ g3,
+                                                                int ldg, int H, int W, int C8, int CS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int slabs = (C8 + CS - 1) / CS;
+    const int b = blockIdx.x / slabs, slab = blockIdx.x - b * slabs;
+    const int c80 = slab * CS, ncs = min(CS, C8 - c80);
+    const int n = H * W * ncs, cap = H * W * CS;
+    Raw8<T>* Z = reinterpret_cast<Raw8<T>*>(smem);
+    Raw8<T>* Ga = Z + cap;                             // incoming gradient of the level being differentiated
+    Raw8<T>* Gb = Ga + cap;                            // ... of the next one (written by this level's gather)
+    uint2* code = reinterpret_cast<uint2*>(Gb + cap);
+    const size_t img = (size_t)b * H * W;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / ncs, cs = i - pix * ncs;
+        raw_load8(g3 + (img + pix) * ldg + (c80 + cs) * 8, Ga[i]);
+    }
+#pragma unroll 1
+    for (int lvl = 2; lvl >= 0; --lvl) {
+        const T* const z = lvl == 2 ? z2 : (lvl == 1 ? z1 : z0);
+        T* const gin = lvl == 2 ? g2 : (lvl == 1 ? g1 : g0);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int pix = i / ncs, cs = i - pix * ncs;
+            raw_load8(z + (img + pix) * ldz + (c80 + cs) * 8, Z[i]);
+        }
+        __syncthreads();                               // Z and Ga complete
+        for (int i = threadIdx.x; i < n; i += 256) {   // argmax code of every OUTPUT pixel (maxpool5_argmax_kernel's scan)
+            const int pix = i / ncs, cs = i - pix * ncs;
+            const int oy = pix / W, ox = pix - oy * W;
+            float best[8];
+            int bc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bc[k] = -1; }
+            for (int dy = 0; dy < 5; ++dy) {
+                const int wy = oy + dy - 2;
+                if (wy < 0 || wy >= H) continue;
+                for (int dx = 0; dx < 5; ++dx) {
+                    const int wx = ox + dx - 2;
+                    if (wx < 0 || wx >= W) continue;
+                    float v[8];
+                    raw_unpack8(Z[(wy * W + wx) * ncs + cs], v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (v[k] > best[k] || bc[k] < 0) { best[k] = v[k]; bc[k] = dy * 5 + dx; }
+                }
+            }
+            uint2 pk;
+            pk.x = (unsigned)bc[0] | ((unsigned)bc[1] << 8) | ((unsigned)bc[2] << 16) | ((unsigned)bc[3] << 24);
+            pk.y = (unsigned)bc[4] | ((unsigned)bc[5] << 8) | ((unsigned)bc[6] << 16) | ((unsigned)bc[7] << 24);
+            code[i] = pk;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {   // gather (maxpool5_gather_kernel's order), accumulate onto gin
+            const int pix = i / ncs, cs = i - pix * ncs;
+            const int yy = pix / W, xx = pix - yy * W;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int oy = yy + dy;
+                if (oy < 0 || oy >= H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int ox = xx + dx;
+                    if (ox < 0 || ox >= W) continue;
+                    const int o = (oy * W + ox) * ncs + cs;
+                    const uint2 pk = code[o];
+                    const unsigned want = (unsigned)((2 - dy) * 5 + (2 - dx));
+                    float gv[8];
+                    raw_unpack8(Ga[o], gv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned cd = ((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xffu;
+                        if (cd == want) acc[k] += gv[k];
+                    }
+                }
+            }
+            T* d = gin + (img + pix) * ldg + (c80 + cs) * 8;
+            float old[8];
+            load8<T>(d, old);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += old[k];
+            store8<T>(d, acc);
+            raw_pack8(acc, Gb[i]);                     // the value as STORED (rounded to T): the next level's incoming gradient
+        }
+        __syncthreads();                               // every reader of Ga / Z / code is done before they are overwritten
+        Raw8<T>* t = Ga; Ga = Gb; Gb = t;
+    }
+}
+
+// Y5M_POOL_TILE (default 0): the tiled forms above where an image x >= 1 piece fits 64 KB of LDS; CS = pieces per workgroup
+static int pool_tile_cs(int H, int W, int C, int dtype, int bytes_per_item_bf16, int bytes_per_item_f32) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("Y5M_POOL_TILE"); on = e ? atoi(e) : 0; }
+    if (!on || C % 8 != 0 || H <= 0 || W <= 0) return 0;
+    const size_t per = (size_t)H * W * (dtype == Y5M_BF16 ? bytes_per_item_bf16 : bytes_per_item_f32);
+    int cs = (int)((64u << 10) / per);
+    if (cs < 1) cs = per <= (150u << 10) ? 1 : 0;
+    if (cs > C / 8) cs = C / 8;
+    if (cs > 8) cs = 8;                                // (enough workgroups: B x C / 64 at least)
+    return cs;
+}
+// 1 when y5m_sppf_pool / y5m_sppf_pool_bwd run their LDS-tiled forms for this shape (Engine.algorithmic_bytes asks)
+extern "C" int y5m_sppf_pool_tiled(int H, int W, int C, int dtype) {
+    return pool_tile_cs(H, W, C, dtype, 2 * 16, 2 * 32) > 0 && pool_tile_cs(H, W, C, dtype, 3 * 16 + 8, 3 * 32 + 8) > 0;
+}
+
+// the whole backward cascade of the SPPF pools (reference model.py:108-110): g2 += bwd(z2; g3), g1 += bwd(z1; g2), g0 += bwd(z0; g1)
+// with z0 = x, z1 = pool(x), z2 = pool(pool(x)). One launch where the tiled form applies, else three y5m_maxpool5_bwd calls.
+extern "C" int y5m_sppf_pool_bwd(const void* z0, const void* z1, const void* z2, int ldz, void* g0, void* g1, void* g2,
+                                 const void* g3, int ldg, int B, int H, int W, int C, void* ws, size_t ws_bytes, int dtype,
+                                 void* stream) {
+    Y5M_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    Y5M_REQUIRE(dtype == Y5M_F32 || dtype == Y5M_BF16, "dtype");
+    const int cs = y5m_sppf_pool_tiled(H, W, C, dtype) ? pool_tile_cs(H, W, C, dtype, 3 * 16 + 8, 3 * 32 + 8) : 0;
+    if (cs > 0) {
+        const int slabs = (C / 8 + cs - 1) / cs;
+        const size_t lds = (size_t)H * W * cs * (dtype == Y5M_BF16 ? 3 * 16 + 8 : 3 * 32 + 8);
+        hipStream_t st = y5m_stream(stream);
+        DISPATCH_T(dtype, {
+            auto kern = sppf_pool_bwd_tile_kernel<T>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(B * slabs)), dim3(256), lds, st, (const T*)z0, (const T*)z1, (const T*)z2, ldz,
+                               (T*)g0, (T*)g1, (T*)g2, (const T*)g3, ldg, H, W, C / 8, cs);
+        })
+        Y5M_CHECK_LAUNCH("sppf_pool_bwd_tile_kernel");
+        return Y5M_OK;
+    }
+    const void* zs[3] = {z0, z1, z2};
+    void* gs[4] = {g0, g1, g2, const_cast<void*>(g3)};
+    for (int lvl = 2; lvl >= 0; --lvl) {
+        const int rc = y5m_maxpool5_bwd(zs[lvl], ldz, gs[lvl + 1], ldg, B, H, W, C, gs[lvl], ldg, 1, ws, ws_bytes, dtype, stream);
+        if (rc != Y5M_OK) return rc;
+    }
     return Y5M_OK;
 }
 

@@ -819,17 +819,21 @@ class Engine:
                 self._consume(cat)            # the three pool backward passes accumulate into slices of d(cat)
 
             def backward():
-                ops = []
                 for _ in range(3):
                     self._written(cat)
                 g = [s.grad for s in sl]
-                # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)   (cascade of model.py:108-110)
-                for lvl in (2, 1, 0):
-                    ops.append((_kind(lambda lvl=lvl: _lib.check(
-                        L.y5m_maxpool5_bwd(sl[lvl].ptr, cat.ld, g[lvl + 1].ptr, g[lvl + 1].ld, x.B, x.H, x.W, c_,
-                                           g[lvl].ptr, g[lvl].ld, 1, _lib.ptr(poolws), poolws.numel(), dt, st()),
-                        "y5m_maxpool5_bwd"), "pool", (3 * x.M * c_ * self.esz, x.M * c_ * self.esz, 0, 0)), ()))
-                return ops
+                # g2 += bwd(p2; g3) ; g1 += bwd(p1; g2) ; g0 += bwd(x; g1)   (cascade of model.py:108-110) as ONE call: one launch
+                # where the library's LDS-tiled form applies (Y5M_POOL_TILE), else the three per-level launches inside it
+                tiled = bool(L.y5m_sppf_pool_tiled(x.H, x.W, c_, dt))
+                nb = x.M * c_ * self.esz
+
+                def pool_bwd():
+                    _lib.check(L.y5m_sppf_pool_bwd(sl[0].ptr, sl[1].ptr, sl[2].ptr, cat.ld, g[0].ptr, g[1].ptr, g[2].ptr, g[3].ptr,
+                                                   g[0].ld, x.B, x.H, x.W, c_, _lib.ptr(poolws), poolws.numel(), dt, st()),
+                               "y5m_sppf_pool_bwd")
+                # tiled: z0..z2, g3 and the three accumulation targets read, the three targets written; per level: z, g and the
+                # target read, the target written
+                return [(_kind(pool_bwd, "pool", ((7 if tiled else 9) * nb, 3 * nb, 0, 0)), ())]
             self._bwd_stack.append(backward)
         return self._cbl(f"{name}.c_out", cat, cout, 1, 1, 0)
 

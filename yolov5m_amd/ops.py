@@ -388,8 +388,8 @@ def bn_silu_backward(dz, y, scale, shift, mean, invstd, dtype="f32"):
 
 def sppf_pool_backward(x, p1, p2, g, dtype="f32"):
     """autograd of the SPPF pool cascade p1 = pool(x), p2 = pool(p1), p3 = pool(p2) (reference model.py:108-110) wrt x:
-    g = (g_x, g_p1, g_p2, g_p3), the gradients arriving at the four concat slices (B,C,H,W). Three native launches
-    (y5m_maxpool5_bwd, accumulating): g_p2 += bwd(p2; g_p3), g_p1 += bwd(p1; g_p2), g_x += bwd(x; g_p1). Returns d(x)."""
+    g = (g_x, g_p1, g_p2, g_p3), the gradients arriving at the four concat slices (B,C,H,W). One native call
+    (y5m_sppf_pool_bwd, accumulating): g_p2 += bwd(p2; g_p3), g_p1 += bwd(p1; g_p2), g_x += bwd(x; g_p1). Returns d(x)."""
     L = _lib.lib()
     dt, tdt, CH, BK = _DT[dtype]
     _lib.require_cuda(x)
@@ -398,8 +398,8 @@ def sppf_pool_backward(x, p1, p2, g, dtype="f32"):
     gn = [to_nhwc(t, tdt) for t in g]
     wsb = L.y5m_maxpool5_bwd_workspace_bytes(B, H, W, C)
     ws = torch.zeros(max(wsb, 1), dtype=torch.uint8, device=x.device)
-    for lvl in (2, 1, 0):
-        _lib.check(L.y5m_maxpool5_bwd(_lib.ptr(src[lvl]), C, _lib.ptr(gn[lvl + 1]), C, B, H, W, C, _lib.ptr(gn[lvl]), C, 1,
-                                      _lib.ptr(ws), wsb, dt, _lib.stream_ptr()), "y5m_maxpool5_bwd")
+    _lib.check(L.y5m_sppf_pool_bwd(_lib.ptr(src[0]), _lib.ptr(src[1]), _lib.ptr(src[2]), C, _lib.ptr(gn[0]), _lib.ptr(gn[1]),
+                                   _lib.ptr(gn[2]), _lib.ptr(gn[3]), C, B, H, W, C, _lib.ptr(ws), wsb, dt, _lib.stream_ptr()),
+               "y5m_sppf_pool_bwd")
     torch.cuda.synchronize()
     return from_nhwc(gn[0])
