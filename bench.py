@@ -230,20 +230,20 @@ def _guarded(name, fn):
         return {"error": f"{name} leg failed: {type(e).__name__}: {str(e)[:300]}"}
 
 
-def roofline_leg(step, model, images, targets, dtype):
+def roofline_leg(step, model, images, targets, dtype, passes=2):
     """rank 0, outside the timed region: HIP-event pairs around every launch of the step (profile_step) -> the `roofline` object"""
     fams = {}
     cls = {"spatial": [0.0, 0.0, 0.0, 0], "pointwise": [0.0, 0.0, 0.0, 0], "fused_pw_bwd": [0.0, 0.0, 0.0, 0]}     # [ms, flop, bytes, launches]
     esz = 2 if dtype == "bf16" else 4
     kernels, insitu = {}, {}
-    for _ in range(2):
+    for _ in range(passes):
         # the step's OWN schedule (weight gradients on the forked stream next to the main stream's kernels), every
         # launch timed by HIP events on the stream it runs on: what a launch costs inside the step
         _f, _c, kern = step.profile_step(images, targets, detail="kernels", overlapped=True)
         for name, ms_, fl, *by in kern:
             k = insitu.setdefault(name, [0.0, 0.0, 0, 0.0])
             k[0] += ms_; k[1] += fl; k[2] += 1; k[3] += by[0] if by else 0.0
-    for _ in range(2):
+    for _ in range(passes):
         # the same launches with the forked stream serialised: per-family times that add up
         fam, convs, kern = step.profile_step(images, targets, detail="kernels")
         for name, ms_, fl, *by in kern:
@@ -271,8 +271,8 @@ def roofline_leg(step, model, images, targets, dtype):
     stem = eng.layers[0]
     dgrad_flops = fwd_flops - 2 * stem.M * stem.cout * stem.cin_real * stem.k * stem.k
     conv_ms, conv_n = fams.get("conv_igemm", (0.0, 1))
-    conv_ms /= 2
-    conv_n //= 2
+    conv_ms /= passes
+    conv_n //= passes
     achieved = (fwd_flops + dgrad_flops) / (conv_ms * 1e-3) / 1e12
     wg_ms, wg_n = fams.get("wgrad", (0.0, 1))
     # headline = the ONE kernel instantiation with the largest share of the step, by summed launch time INSIDE the
@@ -289,10 +289,10 @@ def roofline_leg(step, model, images, targets, dtype):
     traffic, traffic_src = pmc_traffic(dom_name)
 
     def row(n_, v):
-        r_ = {"kernel": n_, "ms_per_step": round(v[0] / 2, 3), "launches_per_step": v[2] // 2,
+        r_ = {"kernel": n_, "ms_per_step": round(v[0] / passes, 3), "launches_per_step": v[2] // passes,
               "achieved_TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
               "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-              "ms_per_step_serialised": round(kernels.get(n_, v)[0] / 2, 3)}
+              "ms_per_step_serialised": round(kernels.get(n_, v)[0] / passes, 3)}
         if v[3] > 0:
             r_.update(bound="hbm", achieved_GBps=round(v[3] / (v[0] * 1e-3) / 1e9, 1),
                       frac=round(v[3] / (v[0] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4))
@@ -302,10 +302,10 @@ def roofline_leg(step, model, images, targets, dtype):
         "achieved": round(dom_ach, 2), "peak": peak, "unit": unit,
         "frac": round(dom_ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "timing": "HIP events around every launch on its own stream, inside the step's overlapped schedule (eager pass)",
-        "launches_per_step": dom_n // 2, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
+        "launches_per_step": dom_n // passes, "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
         "algorithmic_gflop_per_launch": round(dom_fl / max(dom_n, 1) / 1e9, 2),
         "algorithmic_MB_per_launch": round(dom_by / max(dom_n, 1) / 1e6, 2) if hbm else None,
-        "share_of_step_ms": round(dom_ms / 2, 3),
+        "share_of_step_ms": round(dom_ms / passes, 3),
         "achieved_serialised": round(ser_ach, 2), "frac_serialised": round(ser_ach / peak, 4),
         "avg_launch_us_serialised": round(ser_ms * 1e3 / max(ser_n, 1), 2),
         "by_kernel": [row(n_, v) for n_, v in ranked[:8]],
@@ -313,22 +313,22 @@ def roofline_leg(step, model, images, targets, dtype):
                         "achieved_TFLOPs": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                         "launches_per_step": conv_n, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
                         "algorithmic_gflop_per_step": round((fwd_flops + dgrad_flops) / 1e9, 1)},
-        "family_ms_per_step": {k: round(v[0] / 2, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
-        "wgrad_tflops": round(fwd_flops / (wg_ms / 2 * 1e-3) / 1e12, 2) if wg_ms else None,
+        "family_ms_per_step": {k: round(v[0] / passes, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
+        "wgrad_tflops": round(fwd_flops / (wg_ms / passes * 1e-3) / 1e12, 2) if wg_ms else None,
         # the same launches split by what bounds them: k x k taps (MFMA) vs 1x1 (HBM: every input and output
         # element moves once, M*(Cin+Cout) elements + the weights)
         "by_class": {
-            "spatial_convs(taps>1)": {"bound": "mfma", "launches_per_step": cls["spatial"][3] // 2,
-                                      "ms_per_step": round(cls["spatial"][0] / 2, 3),
+            "spatial_convs(taps>1)": {"bound": "mfma", "launches_per_step": cls["spatial"][3] // passes,
+                                      "ms_per_step": round(cls["spatial"][0] / passes, 3),
                                       "achieved_TFLOPs": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9, 1),
                                       "frac": round(cls["spatial"][1] / max(cls["spatial"][0], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)},
-            "pointwise_convs(1x1)": {"bound": "hbm", "launches_per_step": cls["pointwise"][3] // 2,
-                                     "ms_per_step": round(cls["pointwise"][0] / 2, 3),
+            "pointwise_convs(1x1)": {"bound": "hbm", "launches_per_step": cls["pointwise"][3] // passes,
+                                     "ms_per_step": round(cls["pointwise"][0] / passes, 3),
                                      "achieved_GBps": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6, 1),
                                      "achieved_TFLOPs": round(cls["pointwise"][1] / max(cls["pointwise"][0], 1e-9) / 1e9, 1),
                                      "frac": round(cls["pointwise"][2] / max(cls["pointwise"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
             "fused_pointwise_backward(bn apply + dgrad + wgrad)": {
-                "bound": "hbm", "launches_per_step": cls["fused_pw_bwd"][3] // 2, "ms_per_step": round(cls["fused_pw_bwd"][0] / 2, 3),
+                "bound": "hbm", "launches_per_step": cls["fused_pw_bwd"][3] // passes, "ms_per_step": round(cls["fused_pw_bwd"][0] / passes, 3),
                 "achieved_GBps": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6, 1),
                 "achieved_TFLOPs": round(cls["fused_pw_bwd"][1] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e9, 1),
                 "frac": round(cls["fused_pw_bwd"][2] / max(cls["fused_pw_bwd"][0], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4)},
@@ -545,7 +545,7 @@ def main():
                 "frac_of_hbm_peak": round(rate / PEAK_HBM_GBPS, 4), "GB_by_kind": {k: round(v[0] / 1e9, 3) for k, v in top}}
     out["step_bytes"] = _guarded("step_bytes", step_bytes)
     if not args.no_roofline:
-        out["roofline"] = _guarded("roofline", lambda: roofline_leg(step, model, images, targets, args.dtype))
+        out["roofline"] = _guarded("roofline", lambda: roofline_leg(step, model, images, targets, args.dtype, args.leg_iters or 2))
     if world == 1 and not args.no_detect:
         del step, images
         model._engines = {}

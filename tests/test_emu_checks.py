@@ -93,7 +93,7 @@ def test_round4_kernel_forms_green_on_the_executor():
     """the five round-4 kernel rewrites sit behind Y5M_R4_KERNELS (default 0 = the round-3 forms that ran on hardware; csrc/
     y5m_common.h). The regular executor suite runs the default; this runs the op-level cases of those five kernels with all five
     round-4 forms selected (a child: the mask is read once per process), under the uniformity check and deferred LDS-DMA."""
-    e = dict(os.environ, Y5M_R4_KERNELS="31", Y5M_EMU_THREADS="4")
+    e = dict(os.environ, Y5M_R4_KERNELS="31")
     r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "run_gpu_tests.py"), "test_gpu_conv",
                         "--only=wgrad_rows|bwd_pw_fused|bwd_stem_fused|bn_act_and_backward"], env=e, capture_output=True, text=True, timeout=1500)
     lines = [l for l in r.stdout.splitlines() if " test_" in l]

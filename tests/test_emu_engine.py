@@ -257,3 +257,78 @@ def test_dp_overlapped_schedule_gloo_ranks(world):
         assert same, "parameters differ across ranks after the optimizer"
         assert moved > 0
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_eval_plan_packs_once_per_weight_version(monkeypatch):
+    """an inference plan packs its weights / folds BatchNorm once per weight VERSION (Engine.forward): the second forward of the same
+    weights launches no pack; an in-place edit of a parameter, of a running statistic, a load_state_dict and a native train step
+    (which writes the masters through raw pointers) each make the next inference forward pack again -- and its logits equal those of
+    a model built fresh from the same state"""
+    from emu.harness import emulated
+    from yolov5m_amd import config
+    from yolov5m_amd.engine import Engine
+    from yolov5m_amd.model import YOLOV5m
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.synth import synth_images, synth_labels, synth_state_dict
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    packs = []
+    real = Engine._run
+
+    def counting(lst, timeline=None):
+        if lst and getattr(lst[0][0], "kind", None) == "pack_weights":
+            packs.append(1)
+        return real(lst, timeline)
+    monkeypatch.setattr(Engine, "_run", staticmethod(counting))
+
+    def fresh(sd):
+        f = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+        f.load_state_dict(sd, strict=True)
+        f.compute_dtype = "bf16"
+        f.eval()
+        with torch.no_grad():
+            return [o.clone() for o in f(x)]
+    with emulated():
+        x = synth_images(1, 64, 64, seed="ver/img")
+        m = _model()
+        m.eval()
+        with torch.no_grad():
+            o1 = [o.clone() for o in m(x)]
+            n1 = len(packs)
+            o2 = [o.clone() for o in m(x)]
+        assert n1 == 1 and len(packs) == 1 and all(torch.equal(a, b) for a, b in zip(o1, o2))
+        with torch.no_grad():
+            m.backbone[0].cbl[0].weight.mul_(0.5)                    # in-place edit of a parameter
+            o3 = [o.clone() for o in m(x)]
+        assert len(packs) == 2 and not torch.equal(o3[0], o1[0])
+        with torch.no_grad():
+            m.backbone[1].cbl[1].running_var.mul_(2.0)               # ... of a running statistic
+            o4 = [o.clone() for o in m(x)]
+        assert len(packs) == 3 and not torch.equal(o4[0], o3[0])
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        ref = fresh(sd)
+        assert all(torch.equal(a, b) for a, b in zip(o4, ref))
+        with torch.no_grad():
+            m.backbone[0].cbl[0].weight.data.mul_(2.0)              # behind torch's back (a fresh .data view has its own counter) ...
+            n = len(packs)
+            m(x)
+            assert len(packs) == n                                   # ... is invisible (documented) until the model is told
+            m.mark_weights_changed()
+            m(x)
+            assert len(packs) == n + 1
+        packs.clear()
+        m.load_state_dict(synth_state_dict(), strict=True)              # load_state_dict
+        with torch.no_grad():
+            o5 = [o.clone() for o in m(x)]
+        assert len(packs) >= 1 and all(torch.equal(a, b) for a, b in zip(o5, o1))
+        # a native train step: masters, running statistics and num_batches_tracked written by kernels
+        m.train()
+        st = NativeTrainStep(m, ComputeLoss(m), nt_max=64)
+        st.step(synth_images(2, 64, 64, seed="ver/t"), synth_labels(2, 4, seed="ver/l"))
+        m.eval()
+        packs.clear()
+        with torch.no_grad():
+            o6 = [o.clone() for o in m(x)]
+            o7 = [o.clone() for o in m(x)]
+        assert len(packs) == 1 and not torch.equal(o6[0], o1[0]) and torch.equal(o6[0], o7[0])
+        ref = fresh({k: v.clone() for k, v in m.state_dict().items()})
+        assert all(torch.equal(a, b) for a, b in zip(o6, ref))

@@ -1275,9 +1275,25 @@ class Engine:
         buffers (B,naxs,ny,nx,5+nc) f32 -- engine-owned, overwritten by the next forward."""
         if images is not None:
             self.x_in.copy_(images)
-        self._run(self.pack)
+        # Training plans re-pack every step (the masters have just been updated). An INFERENCE plan packs its bf16 weight rows and
+        # folds BatchNorm once per weight version: the pack launch reads all 85 MB of masters and is ~4 % of an eval forward at
+        # B = 32 @ 640x640. The version is torch's own in-place counters of the parameters and the running-statistics buffer
+        # (load_state_dict, optimizers, manual edits all bump them) plus the counter of num_batches_tracked, which every training
+        # forward bumps -- the native optimizer and BatchNorm kernels write through raw pointers and bump nothing themselves.
+        key = None if self.training else self._weights_key()
+        if key is None or key != getattr(self, "_packed_key", None):
+            self._run(self.pack)
+            self._packed_key = key
         self._run(self.fwd)
         return self.outs
+
+    def _weights_key(self):
+        m = self.model
+        # (a Parameter is `p.data = view of the flat buffer`: it keeps its OWN version counter, so every parameter is asked; the
+        #  running statistics are plain views of their flat buffer and share its counter; counters only grow, so the sum moves
+        #  whenever any of them does)
+        return (m.flat_params.data_ptr(), sum(p._version for p in m._param_list) + m.flat_params._version,
+                m._flat_stats._version, m._nbt._version, getattr(m, "_weights_epoch", 0))
 
     def backward(self, grads=None):
         """grads: 3 tensors d(loss)/d(logits) (or None if already written into head gout buffers).

@@ -426,6 +426,12 @@ class YOLOV5m(nn.Module):
         self._engines[key] = eng               # (re-)insert at the most-recently-used end
         return eng
 
+    def mark_weights_changed(self):
+        """Inference plans pack their bf16 weight rows and fold BatchNorm once per weight version, read from torch's in-place
+        counters (Engine._weights_key). Code that writes parameters or running statistics behind torch's back -- a custom kernel
+        through data_ptr(), a write through a fresh `.data` view -- calls this to make the next inference forward pack again."""
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+
     # ------------------------------------------------------------------ reference API
     def forward(self, x):
         assert x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0, "Width and Height aren't divisible by 32!"
