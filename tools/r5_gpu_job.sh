@@ -14,13 +14,14 @@ bash tools/profile_round.sh > $O/prof_round.log 2>&1; tail -12 $O/prof_round.log
 for i in 2 3; do python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/suite_$i.txt; tail -1 $O/suite_$i.txt; done
 # 4. A/B inside the step, one bit at a time: the five round-4 kernel forms (Y5M_R4_KERNELS) -- op tests with all five on first.
 #    Decision rule: what is not faster INSIDE THE STEP stays off.
-bash tools/ab_r4_kernels.sh 3 > $O/ab_r4_kernels.log 2>&1; cat gpurun_out/ab_r4_kernels/r4_forms_op_tests.txt gpurun_out/ab_r4_kernels/step.txt
+AB_TAG=r4 bash tools/ab_r4_kernels.sh 3 > $O/ab_r4_kernels.log 2>&1; cat gpurun_out/ab_r4_kernels/r4_forms_op_tests.txt gpurun_out/ab_r4_kernels/step.txt
 #    + the round-5 LDS-tiled SPPF pooling (Y5M_POOL_TILE=1: forward 2 launches -> 1, backward 6 -> 1; bit-identical results):
 #      its GPU test, the pooling kernels' times under rocprofv3, and the step A/B
 Y5M_POOL_TILE=0 timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -k "sppf_pool" 2>&1 | tail -2 | tee $O/pool_tile_test.txt
 (cd /tmp && export TMPDIR=/tmp && for m in 0 1; do Y5M_POOL_TILE=$m timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/pool_prof$m -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-detect > /dev/null 2>&1; done)
 for m in 0 1; do f=$(find $O/pool_prof$m -name "*kernel_stats.csv" | head -1); echo "== Y5M_POOL_TILE=$m"; grep -i "sppf\|maxpool" "$f" | cut -c1-160; done | tee $O/pool_tile_kernels.txt; rm -rf $O/pool_prof0 $O/pool_prof1
-bash tools/ab_step.sh 3 "default|" "pool_tile|Y5M_POOL_TILE=1" 2>&1 | tail -6 | tee $O/ab_pool_tile.txt
+AB_TAG=pool bash tools/ab_step.sh 3 "default|" "pool_tile|Y5M_POOL_TILE=1" 2>&1 | tail -6 | tee $O/ab_pool_tile.txt
+python tools/ab_summary.py gpurun_out/ab_step/ab_r4.txt gpurun_out/ab_step/ab_pool.txt | tee $O/ab_summary.txt
 # 5. dp_parity soak: which bound fires, and the distribution of every checked value (20 standalone runs)
 bash tools/dp_soak.sh 20 $O/dp_soak > $O/dp_soak.txt 2>&1; tail -1 $O/dp_soak.txt
 # 6. the graph-destroy hunt (stand-alone HIP reproducer + the known reproducer under the heap checker)
