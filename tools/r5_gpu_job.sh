@@ -5,13 +5,13 @@
 # Blocks 1-3 ~25 min, 4 ~25 min, 5-6 ~30 min, 7-8 ~20 min. A shorter --timeout cuts the tail.
 O=gpurun_out/r5; mkdir -p $O
 # 1. HEAD's GPU suite once WITHOUT -x (every failure listed), smoke, the bench line with all its legs
-python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 > $O/suite_1.txt; tail -1 $O/suite_1.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.txt
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo; tail -3 $O/bench.err
+timeout 2400 python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 > $O/suite_1.txt; tail -1 $O/suite_1.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.txt
+timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo; tail -3 $O/bench.err
 # 2. the round's rocprof evidence set (kernel stats, HBM PMC, conv PMC inside the step, per-layer table) -> copy to profiles/r05_*
 bash tools/profile_round.sh > $O/prof_round.log 2>&1; tail -12 $O/prof_round.log
 # 3. suite twice more (three consecutive greens with the commit hash)
-for i in 2 3; do python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/suite_$i.txt; tail -1 $O/suite_$i.txt; done
+for i in 2 3; do timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/suite_$i.txt; tail -1 $O/suite_$i.txt; done
 # 4. A/B inside the step, one bit at a time: the five round-4 kernel forms (Y5M_R4_KERNELS) -- op tests with all five on first.
 #    Decision rule: what is not faster INSIDE THE STEP stays off.
 AB_TAG=r4 bash tools/ab_r4_kernels.sh 3 > $O/ab_r4_kernels.log 2>&1; cat gpurun_out/ab_r4_kernels/r4_forms_op_tests.txt gpurun_out/ab_r4_kernels/step.txt
