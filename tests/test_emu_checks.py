@@ -150,3 +150,20 @@ def test_pool_tiled_forms_bit_identical_on_the_executor(tmp_path):
     for s, t in zip(outs["sep"], outs["tiled"]):
         assert np.array_equal(s["a"], t["a"]) and np.array_equal(s["b"], t["b"])
         assert np.abs(s["b"]).max() > 0
+
+
+def test_halo_two_stage_ring_green_on_the_executor():
+    """Y5M_CONV_HALO_NS2=1 (default 0; csrc/y5m_conv_halo.hip): images 45..88 pixels wide -- the 80x80 stage of a 1280x1280 model --
+    on the halo kernel with a TWO-stage weight ring (three stages + two patch buffers exceed the LDS, so these shapes ran tiled).
+    The executor twin of tests/test_gpu_conv.py::test_halo_two_stage_ring_wide_images_subprocess: three "CUs", so every workgroup walks
+    several tiles and the ring's parity is carried across slabs and tiles; waves visited in random order."""
+    body = ("import test_dispatch_cpu as D\n    from yolov5m_amd._lib import EPI_RAW_STATS, EPI_DGRAD\n"
+            "    assert D._conv_name(128, 192, 80, 80, 192, 3, 1, EPI_RAW_STATS) == 'conv_halo_kernel<6,0,ns2>'\n"
+            "    assert D._conv_name(128, 192, 80, 80, 192, 3, 1, EPI_DGRAD) == 'conv_halo_kernel<6,3,ns2>'\n"
+            "    assert D._conv_name(64, 192, 40, 40, 192, 3, 1, EPI_RAW_STATS) == 'conv_halo_kernel<6,0>'\n"
+            "    for case in T.HALO_WIDE_CASES:\n        T.test_halo_wide_forward_and_dgrad(case)")
+    c = _child(body, Y5M_CONV_HALO_NS2=1, Y5M_EMU_CUS=3, Y5M_EMU_WAVE_ORDER=7)
+    assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-1500:]
+    off = _child("import test_dispatch_cpu as D\n    from yolov5m_amd._lib import EPI_RAW_STATS\n"
+                 "    assert D._conv_name(128, 192, 80, 80, 192, 3, 1, EPI_RAW_STATS).startswith('conv_igemm_kernel')")
+    assert off.returncode == 0 and "CHILD-PASSED" in off.stdout, off.stderr[-800:]

@@ -39,7 +39,7 @@ SELECT = {
     "test_gpu_conv": {
         # subprocess tests start a fresh interpreter on the real device; conv_multi builds a model on "cuda"
         "test_gemm8_small_shapes_subprocess": None, "test_bn_unfused_engine_subprocess": None,
-        "test_halo_96_channel_tile_subprocess": None,
+        "test_halo_96_channel_tile_subprocess": None, "test_halo_two_stage_ring_wide_images_subprocess": None,
         "test_gemm8_forward_epilogues": lambda kw: _elems(kw["case"]) < _MAX,
         "test_gemm8_bn_accumulator_rows": lambda kw: _elems(kw["case"]) < _MAX,
         "test_gemm8_dgrad": lambda kw: _elems(kw["case"]) < _MAX,

@@ -97,18 +97,20 @@ HALO_CASES = [
 ]
 
 
-def _halo_expected(Cin, N):
-    """the library's dispatch rule (y5m_conv_halo.hip halo_geom): 192-channel tiles (Y5M_CONV_HALO=0 turns the kernel off)"""
+def _halo_expected(Cin, N, W=0):
+    """the library's dispatch rule (y5m_conv_halo.hip halo_geom): 192-channel tiles (Y5M_CONV_HALO=0 turns the kernel off); images
+    wider than 44 pixels only with the two-stage weight ring (Y5M_CONV_HALO_NS2=1, up to 88)"""
     import os
     lvl = int(os.environ.get("Y5M_CONV_HALO", "1"))
-    return "halo" if lvl >= 1 and N % 192 == 0 and Cin % 64 == 0 else None
+    wmax = 88 if os.environ.get("Y5M_CONV_HALO_NS2") == "1" else 44
+    return "halo" if lvl >= 1 and N % 192 == 0 and Cin % 64 == 0 and W <= wmax else None
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_halo_forward_stats_and_epilogue(case):
     from yolov5m_amd import ops
     B, Cin, H, W, Cout = case
-    want = _halo_expected(Cin, Cout)
+    want = _halo_expected(Cin, Cout, W)
     x = _q(_rand((B, Cin, H, W), 61), "bf16")
     w = _q(_rand((Cout, Cin, 3, 3), 62, -0.1, 0.1), "bf16")
     ref = F.conv2d(x, w, None, 1, 1)
@@ -126,6 +128,49 @@ def test_halo_forward_stats_and_epilogue(case):
     assert _relerr(got2, ref2) < TOL["bf16"]
 
 
+# images 45..88 pixels wide (the 80x80 stage of a 1280x1280 model): two patch buffers + THREE weight stages exceed the LDS, so
+# these shapes run on the tiled kernel unless Y5M_CONV_HALO_NS2=1 selects the halo kernel's two-stage ring (round 5, default off)
+HALO_WIDE_CASES = [(1, 192, 10, 80, 192), (2, 64, 9, 56, 192), (1, 384, 6, 88, 384), (3, 192, 13, 47, 192)]
+
+
+def test_halo_two_stage_ring_wide_images_subprocess():
+    """Y5M_CONV_HALO_NS2=1 in a child (the knob is read once): forward with statistics, the fused inference epilogue and the three
+    data-gradient modes of HALO_WIDE_CASES on conv_halo_kernel<6,*,ns2>; Y5M_PERSIST_CUS=3 makes every workgroup walk several
+    tiles, so the ring's parity is carried across slabs and tiles"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_CONV_HALO_NS2") == "1":
+        pytest.skip("already the child")
+    env = dict(os.environ, Y5M_CONV_HALO_NS2="1", Y5M_PERSIST_CUS="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "halo_wide"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", HALO_WIDE_CASES)
+def test_halo_wide_forward_and_dgrad(case):
+    """the wide-image cases through the same checks as HALO_CASES; which kernel runs them depends on Y5M_CONV_HALO_NS2 (the child
+    of test_halo_two_stage_ring_wide_images_subprocess asserts it is the halo kernel's two-stage form)"""
+    import os
+    from yolov5m_amd import ops
+    ns2 = os.environ.get("Y5M_CONV_HALO_NS2") == "1"
+    B, Cin, H, W, Cout = case
+    x = _q(_rand((B, Cin, H, W), 61), "bf16")
+    w = _q(_rand((Cout, Cin, 3, 3), 62, -0.1, 0.1), "bf16")
+    ref = F.conv2d(x, w, None, 1, 1)
+    got, s1, s2 = ops.conv_forward_stats(x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    assert (ops.LAST_KERNEL == "halo") == ns2, ops.LAST_KERNEL
+    assert _relerr(got.cpu(), ref) < TOL["bf16"], _relerr(got.cpu(), ref)
+    np.testing.assert_allclose(s1.cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.02 * float(ref.abs().max()) * 8)
+    np.testing.assert_allclose(s2.cpu().numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.05)
+    sc, sh = _rand((Cout,), 63, 0.5, 1.5), _rand((Cout,), 64, -0.2, 0.2)
+    res = _q(_rand((B, Cout, H, W), 65), "bf16")
+    ref2 = F.silu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res
+    got2 = ops.conv_forward(x.to(DEV), w.to(DEV), 1, 1, "bf16", scale=sc.to(DEV), shift=sh.to(DEV), act=True, res=res.to(DEV)).cpu()
+    assert _relerr(got2, ref2) < TOL["bf16"]
+    for mode in ("plain", "init", "src"):
+        test_halo_dgrad(case, mode)
+
+
 @pytest.mark.parametrize("mode", ["plain", "init", "src"])
 @pytest.mark.parametrize("case", HALO_CASES[:6])
 def test_halo_dgrad(case, mode):
@@ -141,7 +186,7 @@ def test_halo_dgrad(case, mode):
         extra = _q(_rand((B, Cin, H, W), 68), "bf16")
         ref = ref + extra
         kw = {"init": extra.to(DEV)} if mode == "init" else {"src": extra.to(DEV)}
-    want = _halo_expected(Cout, Cin)               # the data gradient has Cout input and Cin output channels
+    want = _halo_expected(Cout, Cin, W)            # the data gradient has Cout input and Cin output channels
     got = ops.conv_dgrad(dy.to(DEV), w.to(DEV), (H, W), 1, 1, "bf16", **kw).cpu()
     assert want is None or ops.LAST_KERNEL == want
     assert _relerr(got, ref) < TOL["bf16"], _relerr(got, ref)

@@ -22,6 +22,16 @@ Y5M_POOL_TILE=0 timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -
 for m in 0 1; do f=$(find $O/pool_prof$m -name "*kernel_stats.csv" | head -1); echo "== Y5M_POOL_TILE=$m"; grep -i "sppf\|maxpool" "$f" | cut -c1-160; done | tee $O/pool_tile_kernels.txt; rm -rf $O/pool_prof0 $O/pool_prof1
 AB_TAG=pool bash tools/ab_step.sh 3 "default|" "pool_tile|Y5M_POOL_TILE=1" 2>&1 | tail -6 | tee $O/ab_pool_tile.txt
 python tools/ab_summary.py gpurun_out/ab_step/ab_r4.txt gpurun_out/ab_step/ab_pool.txt | tee $O/ab_summary.txt
+#    + the halo kernel's two-stage weight ring for images 45..88 pixels wide (Y5M_CONV_HALO_NS2=1; BASELINE configs[4]: the ten
+#      192 -> 192 3x3 layers of the 80x80 stage at 1280x1280 = 21 % of the forward's FLOPs, today on the tiled kernel): its GPU test,
+#      the layer alone, and the detect leg's forward_1280 with the knob off / on
+timeout 900 python -m pytest tests/test_gpu_conv.py -m gpu -q -k "halo_two_stage or halo_wide" 2>&1 | tail -2 | tee $O/halo_ns2_test.txt
+for m in 0 1; do echo "== 192 -> 192 3x3 @ 80x80, B = 128, alone: Y5M_CONV_HALO_NS2=$m" | tee -a $O/halo_ns2_alone.txt
+  Y5M_CONV_HALO_NS2=$m python tools/conv_bench.py fwd 128 192 80 80 192 3 1 30 2>/dev/null | tee -a $O/halo_ns2_alone.txt
+  Y5M_CONV_HALO_NS2=$m python tools/conv_bench.py dgrad 128 192 80 80 192 3 1 30 2>/dev/null | tee -a $O/halo_ns2_alone.txt; done
+for m in 0 1; do Y5M_CONV_HALO_NS2=$m timeout 900 python bench.py --steps 3 --warmup 2 --no-roofline --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('Y5M_CONV_HALO_NS2=$m forward_1280', d['detect'].get('forward_1280'))" | tee -a $O/halo_ns2_detect.txt; done
 # 5. dp_parity soak: which bound fires, and the distribution of every checked value (20 standalone runs)
 bash tools/dp_soak.sh 20 $O/dp_soak > $O/dp_soak.txt 2>&1; tail -1 $O/dp_soak.txt
 # 6. the graph-destroy hunt (stand-alone HIP reproducer + the known reproducer under the heap checker)

@@ -35,7 +35,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define HL_THREADS 512
 #define HL_TP 256                 // pixels per tile
-#define HL_NS 3                   // weight ring stages
+#define HL_NS 3                   // weight ring stages (template parameter NS of the kernel: 3, or 2 for wide images -- see halo_geom)
 
 struct HaloArgs {
     int PR8;                      // patch rows, rounded up to the 8-row DMA piece
@@ -45,6 +45,7 @@ struct HaloArgs {
     int tiles_n, total;           // channel tiles per pixel tile, work items
     int Mtot;                     // B*H*W
     int stat_rows;                // rows of the statistics buffer (4 per pixel tile)
+    int ns;                       // weight ring stages of the instantiation that fits the LDS: 3, or 2 (Y5M_CONV_HALO_NS2)
 };
 
 template <int NF>
@@ -151,7 +152,7 @@ _Pragma("unroll") \
                     en0 = n0; \
                     pending = true; \
                 } \
-                const unsigned wbase = wl + (unsigned)((t % 3) * WB); \
+                const unsigned wbase = wl + (NS == 3 ? (unsigned)((t % 3) * WB) : wst); \
                 const unsigned wsrc = t + 2 < 9 ? wso : nwso; \
                 const int wtap = t + 2 < 9 ? t + 2 : t + 2 - 9; \
                 const int tp = (t + 8) % 9;                       /* the unit whose loads are stored now */ \
@@ -166,7 +167,7 @@ _Pragma("unroll") \
                     for (int a = 0; a < NF; ++a) { HL_LD(wb1[a], (wbase ^ 64u) + (unsigned)(a * 2048)) } \
                 } \
                 store_patch_piece(preg, tp, tp == 8 ? cpst_v : npst_v); \
-                store_weights(wreg, (tp + 2) % 9, 0, NWP); \
+                store_weights(wreg, (tp + 2) % 9, 0, NWP, wst ^ (unsigned)WB); \
                 HL_NEXT_ADDR() \
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                 HL_PRIO(0) \
@@ -182,10 +183,17 @@ _Pragma("unroll") \
                 } else { \
                     load_weights(wreg, wsrc, wtap, 1, NWP); \
                 } \
+                if (NS == 2) wst ^= (unsigned)WB; \
                 HL_PHASE_END() \
             }
 
-template <int NF, int EPI>
+// NS: stages of the weight ring. 3 = the measured form (stage = tap % 3, a compile-time constant of the unrolled taps). 2 (round 5,
+// Y5M_CONV_HALO_NS2, unmeasured): the stage is a scalar that toggles every unit -- the long-K GEMM kernel's ring (y5m_conv_gemm.hip:
+// "two stages are enough"): unit t + 1's weights are stored in the R phase of unit t into the stage unit t - 1 was read from, which
+// both wave groups have left (group A read it two phases, group B one phase earlier, and every phase ends in a barrier). It frees
+// 24 KB of LDS, which is what lets images 45..88 pixels wide -- the 80x80 stage of a 1280x1280 model -- use this kernel at all
+// (their two patch buffers + three stages exceed 160 KB, so they ran on the tiled kernel).
+template <int NF, int EPI, int NS>
 __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams P, const HaloArgs G) {
     constexpr int BN = 2 * NF * 16;                       // channels per tile (2 channel groups of waves)
     constexpr int WB = BN * 128;                          // bytes of one weight stage
@@ -201,7 +209,8 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
     const int PB = G.PR8 * 128;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     // LDS map: [patch 0][patch 1][weight stage 0..2][zero row 128][dummy 1024]
-    const unsigned P_OFF = 0, W_OFF = 2 * PB, Z_OFF = W_OFF + HL_NS * WB, D_OFF = Z_OFF + 128;
+    const unsigned P_OFF = 0, W_OFF = 2 * PB, Z_OFF = W_OFF + NS * WB, D_OFF = Z_OFF + 128;
+    unsigned wst = 0u;                                     // NS == 2: byte offset (0 | WB) of the ring stage the current unit reads
 
     if (tid < 8) *reinterpret_cast<uint4*>(smem + Z_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
@@ -392,11 +401,12 @@ __global__ __launch_bounds__(HL_THREADS) void conv_halo_kernel(const ConvParams 
             if (j >= j0 && j < j1) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[j], soff, 0);
     };
     // ... into ring stage k % 3 (a piece behind the tile's BN rows -- BN = 96, waves 4-7, j = 1 -- goes to the dummy region)
-    auto store_weights = [&](const u32x4 (&wr)[NWP], int k, int j0, int j1) __attribute__((always_inline)) {
+    auto store_weights = [&](const u32x4 (&wr)[NWP], int k, int j0, int j1, unsigned stage2) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NWP; ++j)
             if (j >= j0 && j < j1) {
-                const unsigned dst = wid + 8 * j < BN / 8 ? wst_v + (unsigned)((k % 3) * WB + j * 8192) : D_OFF + lane16;
+                const unsigned stg = NS == 3 ? (unsigned)((k % 3) * WB) : stage2;        // (NS == 2: the stage the NEXT unit reads)
+                const unsigned dst = wid + 8 * j < BN / 8 ? wst_v + stg + (unsigned)(j * 8192) : D_OFF + lane16;
                 *reinterpret_cast<u32x4*>(smem + dst) = wr[j];
             }
     };
@@ -557,8 +567,14 @@ static bool halo_geom(const ConvParams& P, int dtype, HaloArgs& G, int& BN) {
     G.npieces = G.PR8 / 8;
     G.NPU = (G.npieces + 7) / 8;
     if (G.NPU > 8) return false;           // one piece per wave and unit, units 0..7 (a piece issued in unit 8 would not be waited for before the slab switch)
-    const size_t lds = 2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128 + 128 + 1024;
-    if (lds > 160 * 1024) return false;
+    G.ns = HL_NS;
+    if (2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128 + 128 + 1024 > 160 * 1024) {
+        // two patch buffers + three weight stages do not fit (images wider than 44 pixels): a two-stage ring does up to 88
+        static int ns2 = -1;                // Y5M_CONV_HALO_NS2 (default 0: written without a GPU; A/B staged in tools/r5_gpu_job.sh)
+        if (ns2 < 0) { const char* e = getenv("Y5M_CONV_HALO_NS2"); ns2 = e ? atoi(e) : 0; }
+        if (!ns2 || 2 * (size_t)G.PR8 * 128 + 2 * (size_t)BN * 128 + 128 + 1024 > 160 * 1024) return false;
+        G.ns = 2;
+    }
     G.S = S;
     G.tiles_n = (P.N + BN - 1) / BN;
     const int tiles_m = (int)((Mtot + HL_TP - 1) / HL_TP);
@@ -600,11 +616,11 @@ extern "C" int y5m_conv_is_halo(const y5m_conv_args* args, int dtype) {
     return halo_geom(P, dtype, G, BN) ? 1 : 0;
 }
 
-template <int NF, int EPI>
+template <int NF, int EPI, int NS>
 static int launch_halo(const ConvParams& P, const HaloArgs& G, hipStream_t st) {
     constexpr int BN = 2 * NF * 16;
-    const size_t lds = 2 * (size_t)G.PR8 * 128 + HL_NS * (size_t)BN * 128 + 128 + 1024;
-    auto kern = conv_halo_kernel<NF, EPI>;
+    const size_t lds = 2 * (size_t)G.PR8 * 128 + NS * (size_t)BN * 128 + 128 + 1024;
+    auto kern = conv_halo_kernel<NF, EPI, NS>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -612,7 +628,8 @@ static int launch_halo(const ConvParams& P, const HaloArgs& G, hipStream_t st) {
     }
     g_halo_cus = y5m_persistent_cus();
     const int grid = G.total < g_halo_cus ? G.total : g_halo_cus;
-    Y5M_NAME_ONLY(Y5M_OK, "conv_halo_kernel<%d,%d>", NF, EPI);
+    if (NS == 3) { Y5M_NAME_ONLY(Y5M_OK, "conv_halo_kernel<%d,%d>", NF, EPI); }
+    else { Y5M_NAME_ONLY(Y5M_OK, "conv_halo_kernel<%d,%d,ns%d>", NF, EPI, NS); }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(HL_THREADS), lds, st, P, G);
     Y5M_CHECK_LAUNCH("conv_halo_kernel");
     return Y5M_OK;
@@ -624,7 +641,11 @@ int y5m_conv_halo_try(const ConvParams& P, int dtype, hipStream_t st) {
     int BN;
     if (!halo_geom(P, dtype, G, BN)) return 0;
     int r;
-    r = P.epi == EPI_RAW_STATS ? launch_halo<6, EPI_RAW_STATS>(P, G, st)
-      : P.epi == EPI_AFFINE_ACT ? launch_halo<6, EPI_AFFINE_ACT>(P, G, st) : launch_halo<6, EPI_DGRAD>(P, G, st);
+    if (G.ns == 2)
+        r = P.epi == EPI_RAW_STATS ? launch_halo<6, EPI_RAW_STATS, 2>(P, G, st)
+          : P.epi == EPI_AFFINE_ACT ? launch_halo<6, EPI_AFFINE_ACT, 2>(P, G, st) : launch_halo<6, EPI_DGRAD, 2>(P, G, st);
+    else
+        r = P.epi == EPI_RAW_STATS ? launch_halo<6, EPI_RAW_STATS, 3>(P, G, st)
+          : P.epi == EPI_AFFINE_ACT ? launch_halo<6, EPI_AFFINE_ACT, 3>(P, G, st) : launch_halo<6, EPI_DGRAD, 3>(P, G, st);
     return r == Y5M_OK ? 1 : r;
 }
