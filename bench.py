@@ -129,6 +129,17 @@ def forward_leg(model, dev, B=32, size=640, iters=10, warm=3):
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
         out[mode] = {"images_per_sec": round(B / dt, 1), "ms": round(dt * 1e3, 3)}
+        # the forward's own roofline: its algorithmic HBM bytes (every operand of every launch once, Engine.algorithmic_bytes) and its
+        # FLOPs against the time -- at these shapes the bf16 forward is BANDWIDTH-bound (B=32 @ 640 eval: 7.5 GB = 1.5 ms at 5 TB/s
+        # against 0.63 ms of MFMA work at the dense peak), so the HBM fraction is the one to read
+        try:
+            eb = model._engine_for(x).algorithmic_bytes()["forward"]
+            gb = (eb["act_read"] + eb["act_written"] + eb["par_read"] + eb["par_written"]) / 1e9
+            fl = FWD_GFLOP_PER_IMAGE_640 * B * (size / 640.0) ** 2
+            out[mode].update(algorithmic_GB=round(gb, 3), GBps=round(gb / dt, 1), frac_of_hbm_peak=round(gb / dt / PEAK_HBM_GBPS, 4),
+                             TFLOPs=round(fl / dt / 1e3, 1), frac_of_mfma_peak=round(fl / dt / 1e3 / PEAK_BF16_TFLOPS, 4))
+        except Exception as e:  # noqa: BLE001
+            out[mode]["roofline_error"] = f"{type(e).__name__}: {e}"
     model.train(True)
     tag = " (BASELINE.json configs[1])" if (B, size) == (32, 640) else ""
     return {"workload": f"forward only, batch {B} @ {size}x{size}, bf16{tag}", "unit": "images/s", **out}
@@ -205,13 +216,24 @@ def detect_leg(dev, model=None, B=128, size=1280, iters=5, warm=2, model_iters=3
                 tf += e0.elapsed_time(e1) / model_iters
                 td += e1.elapsed_time(e2) / model_iters
                 tn += e2.elapsed_time(e3) / model_iters
+        gb1280 = None
+        try:
+            eb = model._engine_for(x).algorithmic_bytes()["forward"]
+            gb1280 = (eb["act_read"] + eb["act_written"] + eb["par_read"] + eb["par_written"]) / 1e9
+        except Exception:  # noqa: BLE001
+            pass
         model.train(True)
         model._engines = {}
         flops = B * FWD_GFLOP_PER_IMAGE_640 * (size / 640.0) ** 2
         out["forward_1280"] = {"workload": f"model forward (eval, bf16) + decode + NMS (0.25, 0.45), batch {B} @ {size}x{size}, "
                                            "random-init weights", "forward_ms": round(tf, 2),
                                "forward_images_per_sec": round(B / (tf * 1e-3), 1),
-                               "forward_TFLOPs": round(flops / tf, 1), "decode_ms": round(td, 3), "nms_ms": round(tn, 3),
+                               "forward_TFLOPs": round(flops / tf, 1),
+                               # (bandwidth-bound: 119 GB of algorithmic traffic = 24 ms at 5 TB/s against 10 ms of MFMA work)
+                               "forward_algorithmic_GB": round(gb1280, 2) if gb1280 else None,
+                               "forward_GBps": round(gb1280 / (tf * 1e-3), 1) if gb1280 else None,
+                               "forward_frac_of_hbm_peak": round(gb1280 / (tf * 1e-3) / PEAK_HBM_GBPS, 4) if gb1280 else None,
+                               "decode_ms": round(td, 3), "nms_ms": round(tn, 3),
                                "end_to_end_images_per_sec": round(B / ((tf + td + tn) * 1e-3), 1),
                                "end_to_end_boxes_per_sec": round(B * N / ((tf + td + tn) * 1e-3)),
                                "kept_per_image": round(float(cnt.float().mean()), 1)}

@@ -85,3 +85,24 @@ def test_eval_plan_has_a_traffic_figure_on_every_launch():
         e = eng.algorithmic_bytes()
         assert e["backward"]["launches"] == 0 and e["forward"]["launches"] == len(eng.fwd)
         assert e["forward"]["act_written"] > 0 and e["pack"]["par_written"] > 0
+
+
+@pytest.mark.skipif(not _DEFAULT_ENV, reason="a Y5M_* knob is set")
+def test_inference_forward_is_bandwidth_bound_by_its_own_bytes():
+    """BASELINE.json configs[1] (forward only, B = 32 @ 640x640, bf16, inference mode): 7.51 GB of algorithmic HBM traffic = 1.5 ms at
+    the 5 TB/s a device copy reaches, against 1.56 TFLOP = 0.63 ms at the dense bf16 MFMA peak: the forward legs of bench.py are
+    held against the HBM roofline, not the MFMA one"""
+    from emu.harness import emulated
+    from yolov5m_amd import config
+    from yolov5m_amd.model import YOLOV5m
+    with emulated():
+        m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+        m.compute_dtype = "bf16"
+        m.eval()
+        m.flatten_parameters()
+        eng = m._engine_for(torch.empty((2, 3, 640, 640), device="meta"))
+        f = eng.algorithmic_bytes()["forward"]
+        gb = ((f["act_read"] + f["act_written"]) * 16 + f["par_read"] + f["par_written"]) / 1e9
+        assert abs(gb - 7.51) < 0.02, gb
+        t_hbm, t_mfma = gb / 5e3, 32 * 48.872e9 / 2.5e15
+        assert t_hbm > 2 * t_mfma
