@@ -3,6 +3,8 @@
 (Engine.algorithmic_bytes: every operand of every launch moved once; no GPU involved -- the plan is built at B = 2 on the CPU
 executor's library and rescaled, activation bytes being proportional to the batch), next to the PMC-measured traffic of the last
 committed profiles/r*_pmc_bench.json, and the forward BatchNorm passes a consumer-side fusion could drop.
+Last section: per-launch roofline FLOORS of the train and inference plans -- sum over launches of max(bytes / 5 TB/s, FLOP / 2.5 PFLOP/s)
+(5 TB/s = what a device copy reaches on these boxes, tools/read_bw.py; 2.5 PFLOP/s = dense bf16 MFMA peak).
 usage: python tools/traffic_report.py > profiles/rNN_step_bytes.txt"""
 import glob
 import json
@@ -87,3 +89,42 @@ with emulated():
           f"residual / pool / upsample readers not checked): {drop / 1e9:.3f} GB = {100.0 * drop / r['total_bytes']:.1f} % of the step")
     for name, nb, users in rows:
         print(f"  {name:28s} {nb / 1e9:6.3f} GB  -> {', '.join(users)}")
+
+
+# ---- per-launch roofline floors ------------------------------------------------------------------------------------------------
+HBM, MFMA = 5.0e12, 2.5e15
+
+
+def floor(B_plan, S, B, training):
+    with emulated():
+        mm = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+        mm.compute_dtype = "bf16"
+        mm.train(training)
+        mm.flatten_parameters()
+        e = mm._engine_for(torch.empty((B_plan, 3, S, S), device="meta"))
+        sc = B / B_plan
+        tt = tb = tf = 0.0
+        for lst in ([e.fwd, e.bwd] if training else [e.fwd]):
+            for fn, _ in lst:
+                t = getattr(fn, "traffic", (0, 0, 0, 0))
+                by = (t[0] + t[1]) * sc + t[2] + t[3]
+                fl, kind, d = 0.0, getattr(fn, "kind", ""), getattr(fn, "__defaults__", None)
+                if kind == "conv_igemm" and d:
+                    arr = list(d[0]) if hasattr(d[0], "_length_") else [d[0]]
+                    fl = sum(2.0 * a.M * a.N * a.K for a in arr) * sc
+                elif kind == "wgrad" and getattr(fn, "wa", None) is not None:
+                    fl = 2.0 * fn.wa.M * fn.wa.N * fn.wa.th * fn.wa.tw * fn.wa.C * sc
+                elif kind == "bwd_pw":
+                    fl = 4.0 * fn.bp.M * fn.bp.N * fn.bp.C * sc
+                tt += max(by / HBM, fl / MFMA)
+                tb += by
+                tf += fl
+        return tt, tb, tf
+
+
+print("\nper-launch roofline floors (sum over launches of max(bytes / 5 TB/s, FLOP / 2.5 PFLOP/s)); measured = round 3")
+for Bp, S, Bq, tr, meas, what in ((2, 640, 64, True, 25.1, "train forward + backward (loss / optimizer not included), configs[2]"),
+                                  (2, 640, 32, False, 3.69, "inference forward, configs[1]"), (1, 1280, 128, False, 50.3, "inference forward, configs[4]")):
+    t_, b_, f_ = floor(Bp, S, Bq, tr)
+    print(f"  B={Bq:3d} @ {S:4d} {what}: {b_ / 1e9:7.2f} GB, {f_ / 1e12:6.2f} TFLOP; floor {t_ * 1e3:6.2f} ms (pure HBM {b_ / HBM * 1e3:6.2f}, pure MFMA "
+          f"{f_ / MFMA * 1e3:5.2f}); measured {meas} ms = {meas / (t_ * 1e3):.2f}x the floor")
