@@ -87,3 +87,25 @@ def test_conv_default_dispatch(case, fwd, dgrad):
 @pytest.mark.parametrize("case,want", WGRAD_DEFAULTS)
 def test_wgrad_default_dispatch(case, want):
     assert _wgrad_name(*case) == want
+
+
+@pytest.mark.skipif(not _DEFAULT_ENV, reason="a Y5M_CONV* / Y5M_WGRAD* knob is set")
+def test_configs4_80x80_stage_dispatch_is_the_documented_gap():
+    """BASELINE.json configs[4] (B = 128 @ 1280x1280 inference): the ten 192 -> 192 3x3 layers of the 80x80 stage do not fit the halo
+    kernel's LDS image with a three-stage weight ring (2 x (258 + 2 W) x 128 B + 3 x 24 KB = 182 KB at W = 80) and run on the tiled
+    kernel by default; Y5M_CONV_HALO_NS2=1 (round 5, unmeasured) gives them the two-stage ring. The 40x40 stage (384 channels) and
+    every halo-eligible layer of the 640x640 plans fit the three-stage form. (tools/plan_dispatch.py lists whole plans.)"""
+    EPI_AFFINE_ACT = 1
+    assert _conv_name(128, 192, 80, 80, 192, 3, 1, EPI_AFFINE_ACT) == "conv_igemm_kernel<bf16,2,4,4,3,0>"
+    assert _conv_name(128, 384, 40, 40, 384, 3, 1, EPI_AFFINE_ACT) == "conv_halo_kernel<6,1>"
+    for S in range(320, 704, 32):                       # every multi_scale size of the training loop (training_utils.py:11-28)
+        for C, div in ((192, 16), (384, 32)):
+            assert _conv_name(64, C, S // div, S // div, C, 3, 1, EPI_RAW_STATS) == "conv_halo_kernel<6,0>", (S, C)
+    child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import test_dispatch_cpu as D\n"
+             "assert D._conv_name(128, 192, 80, 80, 192, 3, 1, 1) == 'conv_halo_kernel<6,1,ns2>'\n"
+             "assert D._conv_name(64, 192, 40, 40, 192, 3, 1, 0) == 'conv_halo_kernel<6,0>'\n"
+             "assert D._conv_name(2, 192, 12, 96, 192, 3, 1, 0).startswith('conv_igemm_kernel')\n"      # 96 wide: no ring fits
+             ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, Y5M_CONV_HALO_NS2="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
