@@ -104,6 +104,7 @@ def floor(B_plan, S, B, training):
         e = mm._engine_for(torch.empty((B_plan, 3, S, S), device="meta"))
         sc = B / B_plan
         tt = tb = tf = 0.0
+        by_kind = {}
         for lst in ([e.fwd, e.bwd] if training else [e.fwd]):
             for fn, _ in lst:
                 t = getattr(fn, "traffic", (0, 0, 0, 0))
@@ -119,6 +120,9 @@ def floor(B_plan, S, B, training):
                 tt += max(by / HBM, fl / MFMA)
                 tb += by
                 tf += fl
+                r_ = by_kind.setdefault(kind or getattr(fn, "__name__", "other"), [0.0, 0.0, 0.0, 0])
+                r_[0] += max(by / HBM, fl / MFMA); r_[1] += by; r_[2] += fl; r_[3] += 1
+        floor.by_kind = by_kind
         return tt, tb, tf
 
 
@@ -128,3 +132,17 @@ for Bp, S, Bq, tr, meas, what in ((2, 640, 64, True, 25.1, "train forward + back
     t_, b_, f_ = floor(Bp, S, Bq, tr)
     print(f"  B={Bq:3d} @ {S:4d} {what}: {b_ / 1e9:7.2f} GB, {f_ / 1e12:6.2f} TFLOP; floor {t_ * 1e3:6.2f} ms (pure HBM {b_ / HBM * 1e3:6.2f}, pure MFMA "
           f"{f_ / MFMA * 1e3:5.2f}); measured {meas} ms = {meas / (t_ * 1e3):.2f}x the floor")
+    if tr:
+        # per family: floor against the SERIALISED eager family times of the last committed bench line (forked stream run inline, so the
+        # families add up; the graph-replayed step overlaps the weight gradients with the main stream and is shorter than their sum)
+        lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b64_640_line*.json")))
+        fam = json.load(open(lines[-1]))["roofline"]["family_ms_per_step"] if lines else {}
+        alias = {"apply_fused": ["apply_fused", "apply"], "head_pack": ["head_pack", "pack"]}
+        print(f"    per family (floor from the plan; measured = serialised eager family time, {os.path.basename(lines[-1]) if lines else 'n/a'}):")
+        print(f"    {'family':26s} {'launches':>8s} {'GB':>8s} {'TFLOP':>7s} {'floor ms':>9s} {'measured ms':>12s} {'x floor':>8s}")
+        for k, (ft, fb, ff, n) in sorted(floor.by_kind.items(), key=lambda kv: -kv[1][0]):
+            meas_k = sum(fam.get(a, 0.0) for a in alias.get(k, [k]))
+            if ft * 1e3 < 0.005 and not meas_k:
+                continue
+            print(f"    {k:26s} {n:8d} {fb / 1e9:8.2f} {ff / 1e12:7.2f} {ft * 1e3:9.2f} {meas_k:12.2f} {(meas_k / (ft * 1e3)) if ft > 0 and meas_k else 0:8.2f}")
+
