@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-VARIANTS = ["", "Y5M_R4_KERNELS=31", "Y5M_POOL_TILE=1", "Y5M_BWD_PW=0", "Y5M_BWD_PW_MIN_M=0", "Y5M_BWD_STEM=0", "Y5M_LAZY_RES=0", "Y5M_MERGE_C3=0", "Y5M_WGRAD_DIRECT=0",
+VARIANTS = ["", "Y5M_R4_KERNELS=31", "Y5M_POOL_TILE=1", "Y5M_HEAD_PACK16=1", "Y5M_CONV_HALO_NS2=1", "Y5M_BWD_PW=0", "Y5M_BWD_PW_MIN_M=0", "Y5M_BWD_STEM=0", "Y5M_LAZY_RES=0", "Y5M_MERGE_C3=0", "Y5M_WGRAD_DIRECT=0",
             "Y5M_WGRAD_ROWS=0", "Y5M_WGRAD_AFTER_DGRAD=0", "Y5M_SLOTS=2", "Y5M_SPARSE_HEAD=0", "Y5M_BN_FUSE=0", "Y5M_CONV_HALO=0",
             "Y5M_CONV_GEMM8=0", "Y5M_CONV_GEMM8=1", "Y5M_CONV_PW=0", "Y5M_CONV_MULTI=0"]
 CHILD = r'''

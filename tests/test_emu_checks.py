@@ -167,3 +167,34 @@ def test_halo_two_stage_ring_green_on_the_executor():
     off = _child("import test_dispatch_cpu as D\n    from yolov5m_amd._lib import EPI_RAW_STATS\n"
                  "    assert D._conv_name(128, 192, 80, 80, 192, 3, 1, EPI_RAW_STATS).startswith('conv_igemm_kernel')")
     assert off.returncode == 0 and "CHILD-PASSED" in off.stdout, off.stderr[-800:]
+
+
+def test_head_pack16_bit_identical_on_the_executor(tmp_path):
+    """Y5M_HEAD_PACK16=1 (default 0): the sparse head-gradient pack's objectness rows, two rows per store instruction in 16-byte pieces.
+    The three scales' packed rows (the dy slots) and bias gradients of a train step's head backward (engine, 2 x 64 x 96: 96 / 24 / 6
+    pixels per image and scale -- partial waves, odd row counts) are bit-identical to the 8-byte kernel's, and the sparse-vs-dense op
+    test holds."""
+    import numpy as np
+    body = ("import test_gpu_detect_loss as D\n    D.DEV = 'cpu'\n"
+            "    from yolov5m_amd import config\n    anchors = torch.tensor(config.ANCHORS).float().view(3, -1, 2) / torch.tensor([8., 16., 32.]).view(3, 1, 1)\n"
+            "    for dt in ('bf16', 'f32'):\n        D.test_sparse_head_gradient_path_equals_dense(anchors, dt)\n"
+            "    from yolov5m_amd.model import YOLOV5m\n    from yolov5m_amd.ultralytics_loss import ComputeLoss\n"
+            "    from yolov5m_amd.utils.synth import synth_images, synth_labels, synth_state_dict\n    from yolov5m_amd.utils.training_utils import NativeTrainStep\n"
+            "    m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768)); m.load_state_dict(synth_state_dict(), strict=True)\n"
+            "    m.compute_dtype = 'bf16'; m.train(); m.flatten_parameters()\n"
+            "    st = NativeTrainStep(m, ComputeLoss(m), nt_max=64)\n"
+            "    eng = st.load_inputs(synth_images(2, 64, 96, seed='hp/i'), synth_labels(2, 5, seed='hp/l'))\n"
+            "    kinds = [getattr(op[0], 'kind', None) for op in eng.bwd]\n"
+            "    k = max(i for i, kd in enumerate(kinds) if kd == 'head_pack') + 1\n"
+            "    assert kinds.count('head_pack') == 3\n"
+            "    st._enqueue_fb(eng, bwd_upto=k)                  # forward, loss, the backward list up to the third head pack\n"
+            "    np.savez(OUT, g=m.flat_grads.numpy(), **{f's{i}': t.float().numpy() for i, t in enumerate(eng.scratch2)})")
+    outs = []
+    for tag, env in (("p8", {}), ("p16", {"Y5M_HEAD_PACK16": "1"})):
+        f = str(tmp_path / (tag + ".npz"))
+        c = _child(body.replace("OUT", repr(f)), Y5M_EMU_THREADS=1, **env)          # one OS thread: the f32 atomics of the step in one order
+        assert c.returncode == 0 and "CHILD-PASSED" in c.stdout, c.stderr[-1500:]
+        outs.append(dict(np.load(f)))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert all(np.abs(outs[0][f"s{i}"]).max() > 0 for i in range(3)) and np.abs(outs[0]["g"]).max() > 0

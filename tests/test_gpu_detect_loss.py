@@ -461,6 +461,18 @@ def test_sparse_head_gradient_path_equals_dense(anchors, dtype):
         np.testing.assert_allclose(res["sparse"][2][i].cpu().numpy(), res["dense"][2][i].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_sparse_head_gradient_pack16_subprocess():
+    """Y5M_HEAD_PACK16=1 (default 0; round 5): the objectness rows of the sparse head-gradient pack written two rows per store
+    instruction in 16-byte pieces (head_grad_pack_obj16_kernel) -- the sparse-vs-dense test above in a child with the knob on (pixel
+    counts 720 / 180 / 45: whole waves, a partial wave, an odd last row)"""
+    import os, subprocess, sys
+    if os.environ.get("Y5M_HEAD_PACK16") == "1":
+        pytest.skip("already the child")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "sparse_head_gradient_path_equals_dense"],
+                       env=dict(os.environ, Y5M_HEAD_PACK16="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 3, 20, 20), (3, 3, 1, 1)])
 def test_class_obj_accuracy_counts_bit_exact(shape):
     """y5m_class_obj_accuracy against the reference's masked counting (utils/validation_utils.py:58-68) on random logits with

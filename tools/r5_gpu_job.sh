@@ -20,7 +20,8 @@ AB_TAG=r4 bash tools/ab_r4_kernels.sh 3 > $O/ab_r4_kernels.log 2>&1; cat gpurun_
 Y5M_POOL_TILE=0 timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -k "sppf_pool" 2>&1 | tail -2 | tee $O/pool_tile_test.txt
 (cd /tmp && export TMPDIR=/tmp && for m in 0 1; do Y5M_POOL_TILE=$m timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/pool_prof$m -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-detect > /dev/null 2>&1; done)
 for m in 0 1; do f=$(find $O/pool_prof$m -name "*kernel_stats.csv" | head -1); echo "== Y5M_POOL_TILE=$m"; grep -i "sppf\|maxpool" "$f" | cut -c1-160; done | tee $O/pool_tile_kernels.txt; rm -rf $O/pool_prof0 $O/pool_prof1
-AB_TAG=pool bash tools/ab_step.sh 3 "default|" "pool_tile|Y5M_POOL_TILE=1" 2>&1 | tail -6 | tee $O/ab_pool_tile.txt
+timeout 600 python -m pytest tests/test_gpu_detect_loss.py -m gpu -q -k "sparse_head" 2>&1 | tail -2 | tee $O/head_pack16_test.txt
+AB_TAG=pool bash tools/ab_step.sh 3 "default|" "pool_tile|Y5M_POOL_TILE=1" "head_pack16|Y5M_HEAD_PACK16=1" "both|Y5M_POOL_TILE=1 Y5M_HEAD_PACK16=1" 2>&1 | tail -12 | tee $O/ab_pool_tile.txt
 python tools/ab_summary.py gpurun_out/ab_step/ab_r4.txt gpurun_out/ab_step/ab_pool.txt | tee $O/ab_summary.txt
 #    + the halo kernel's two-stage weight ring for images 45..88 pixels wide (Y5M_CONV_HALO_NS2=1; BASELINE configs[4]: the ten
 #      192 -> 192 3x3 layers of the 80x80 stage at 1280x1280 = 21 % of the forward's FLOPs, today on the tiled kernel): its GPU test,

@@ -1580,6 +1580,50 @@ __global__ __launch_bounds__(256) void head_grad_pack_obj_kernel(const float* __
         }
     }
 }
+// The same rows written TWO at a time with 16-byte pieces (Y5M_HEAD_PACK16, default 0: round 5, written without a GPU). The kernel
+// above writes one 512-byte row per store instruction in 8-byte pieces and takes 0.26 ms per step for 0.28 GB (4.6x its bandwidth
+// floor, profiles/r05_step_bytes.txt): 8-byte accesses run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md) and the loop issues
+// 64 dependent readlane triples. Here lanes 0-31 own row r, lanes 32-63 row r + 1, 8 columns (16 bytes of bf16) per lane; the row's
+// three objectness gradients come through one ds_bpermute each. Same values, same bias sums.
+template <typename T>
+__global__ __launch_bounds__(256) void head_grad_pack_obj16_kernel(const float* __restrict__ gobj, int B, int naxs, int64_t hw, int nch,
+                                                                  T* __restrict__ dyp, int ldp, float* __restrict__ dbias) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t M = (int64_t)B * hw;
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
+    if (m0 >= M) return;
+    const int64_t m = m0 + lane;
+    float go[3] = {0.f, 0.f, 0.f};
+    if (m < M) {
+        const int64_t b = m / hw, pix = m - b * hw;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) go[a] = gobj[(b * naxs + a) * hw + pix];
+    }
+    const int half = lane >> 5, cl = lane & 31;           // which of the two rows, which 8-column piece
+    const int c0 = 4, c1 = nch + 4, c2 = 2 * nch + 4;
+    const bool l0 = cl == (c0 >> 3), l1 = cl == (c1 >> 3), l2 = cl == (c2 >> 3);
+    const bool writer = 8 * cl < ldp;
+    const int nrow = (int)((M - m0) < 64 ? (M - m0) : 64);
+    for (int r = 0; r < nrow; r += 2) {
+        const int rr = r + half;                           // this lane's row (rr < 64 always; rr >= nrow: nothing stored)
+        const float g0 = __shfl(go[0], rr, 64), g1 = __shfl(go[1], rr, 64), g2 = __shfl(go[2], rr, 64);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (l0 && k == (c0 & 7)) v[k] = g0;
+            if (l1 && k == (c1 & 7)) v[k] = g1;
+            if (l2 && k == (c2 & 7)) v[k] = g2;
+        }
+        if (writer && rr < nrow) store8<T>(dyp + (m0 + rr) * ldp + 8 * cl, v);
+    }
+    if (dbias) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float sacc = wave_sum(go[a]);
+            if (lane == 0) atomicAdd(&dbias[a * nch + 4], sacc);
+        }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void head_grad_rows_kernel(const float* __restrict__ dl, const int32_t* __restrict__ owner,
                                                             const int32_t* __restrict__ bagg, const int32_t* __restrict__ count,
@@ -1615,8 +1659,15 @@ extern "C" int y5m_head_grad_pack_sparse(const float* dlogits, const int32_t* ow
     if (dbias && y5m_fill32(dbias, 0u, (size_t)naxs * nch, st) != Y5M_OK) return Y5M_ELAUNCH;
     const int64_t M = (int64_t)B * ny * nx;
     const unsigned grid = (unsigned)((M + 255) / 256);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_obj_kernel<T>, dim3(grid), dim3(256), 0, st, gobj, B, naxs,
-                                         (int64_t)ny * nx, nch, (T*)dyp, ldp, dbias);)
+    static int pack16 = -1;                            // Y5M_HEAD_PACK16 (default 0): two rows per store instruction, 16-byte pieces
+    if (pack16 < 0) { const char* e = getenv("Y5M_HEAD_PACK16"); pack16 = e ? atoi(e) : 0; }
+    if (pack16 && ldp % 8 == 0 && (reinterpret_cast<uintptr_t>(dyp) & 15) == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_obj16_kernel<T>, dim3(grid), dim3(256), 0, st, gobj, B, naxs,
+                                             (int64_t)ny * nx, nch, (T*)dyp, ldp, dbias);)
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_pack_obj_kernel<T>, dim3(grid), dim3(256), 0, st, gobj, B, naxs,
+                                             (int64_t)ny * nx, nch, (T*)dyp, ldp, dbias);)
+    }
     Y5M_CHECK_LAUNCH("head_grad_pack_obj_kernel");
     if (cap > 0) {
         DISPATCH_T(dtype, hipLaunchKernelGGL(head_grad_rows_kernel<T>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, st, dlogits,
