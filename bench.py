@@ -393,6 +393,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--loss", default="ultralytics", choices=["ultralytics", "yolo"],
+                    help="ultralytics = ComputeLoss (the BASELINE.json workload); yolo = YOLO_LOSS, the reference's default loss "
+                         "(train.py:102-106) in the same fused step -- its line is labelled as NOT a BASELINE.json configuration")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -459,7 +462,11 @@ def main():
     model.train()
     model.flatten_parameters()
     parallel.broadcast_parameters(model)
-    loss_fn = ComputeLoss(model)
+    if args.loss == "yolo":
+        from yolov5m_amd.loss import YOLO_LOSS
+        loss_fn = YOLO_LOSS(model, rect_training=False)
+    else:
+        loss_fn = ComputeLoss(model)
     hook = parallel.GradAllReduce(world, timing=True) if world > 1 else None
     step = NativeTrainStep(model, loss_fn, nt_max=B * 8, use_graph=not args.no_graph, grad_hook=hook,
                            overlap=not args.no_overlap)
@@ -468,7 +475,14 @@ def main():
     # device-side loader / y5m_preprocess_u8 does), so step() makes no further copy of the images
     images = step.input_buffer(B, S, S)
     images.copy_(synth_images(B, S, S, seed=f"img/rank{rank}").to(dev))
-    targets = synth_labels(B, 8, seed=f"lab/rank{rank}").to(dev)
+    targets = synth_labels(B, 8, seed=f"lab/rank{rank}")
+    if args.loss == "yolo":
+        # the reference's collate_fn hands YOLO_LOSS host arrays (dataset.py:199-202): the step uploads them (8 boxes x 5 float64
+        # per image) into its static buffers on every call, inside the timed region
+        t = targets.numpy().astype("float64")
+        targets = tuple(t[t[:, 0] == b][:, 1:] for b in range(B))
+    else:
+        targets = targets.to(dev)
 
     first_loss = None
     for _ in range(max(args.warmup, 1)):
@@ -535,14 +549,17 @@ def main():
         "rccl_version": rccl_version, "ranks": idents,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"YOLOv5m full train step (fwd + ComputeLoss + bwd + clip + Adam), batch {B}/GPU @ "
+        "config": {"workload": f"YOLOv5m full train step (fwd + {'YOLO_LOSS' if args.loss == 'yolo' else 'ComputeLoss'} + bwd + clip + Adam), batch {B}/GPU @ "
                                f"{S}x{S}, random-init weights, 8 boxes/image"
-                               + ((" (BASELINE.json configs[2]" + ("/[3]" if world > 1 else "") + ")") if (B, S) == (64, 640)
+                               + (" (NOT BASELINE.json configs[2]: --loss yolo = the reference's default YOLO_LOSS, whose in-place anchor "
+                                  "decay leaves the anchors at zero after the first batches)" if args.loss == "yolo" else
+                                  (" (BASELINE.json configs[2]" + ("/[3]" if world > 1 else "") + ")") if (B, S) == (64, 640)
                                   else " (NOT a BASELINE.json configuration: --batch / --size given)"),
-                   "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph, **first_loss_check(first_loss, B, S, rank),
+                   "loss": args.loss, "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   **(first_loss_check(first_loss, B, S, rank) if args.loss != "yolo" else {"first_step_loss": round(first_loss, 4)}),
                    "final_loss": round(final_loss, 4)},
     }
-    r4 = int(os.environ.get("Y5M_R4_KERNELS", "0") or 0) & 31
+    r4 = int(_lib.lib().y5m_r4_kernel_forms())               # (as the library parsed Y5M_R4_KERNELS, once)
     out["kernel_forms"] = {"Y5M_R4_KERNELS": r4,
                            "note": "bit mask of the round-4 kernel rewrites in use (1 wgrad_rows, 2 bn_act, 4 bwd_stem, 8 bwd_pw, "
                                    "16 bn_bwd_reduce); 0 = the round-3 forms, the ones that passed the GPU suite on hardware"}

@@ -47,6 +47,8 @@ int y5m_device_ok(void);
  * Y5M_PERSIST_CUS (read once per process; yolov5m_amd/parallel.py sets 240 for data-parallel runs so that the collective's
  * kernels find free CUs). New entry point (the reference has no multi-GPU path). */
 int y5m_persistent_cu_count(void);
+/* the Y5M_R4_KERNELS bit mask in use (parsed once per process): which of the default-off round-4 kernel forms the launchers pick */
+int y5m_r4_kernel_forms(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Detect path
@@ -163,6 +165,17 @@ int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const 
                            int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
                            const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
                            float* loss_out, void* ws, size_t ws_bytes, void* stream);
+/* y5m_compute_loss_dense with the sparse gradient of y5m_compute_loss_sparse (the fused train step on the reference's DEFAULT
+ * loss, train.py:102-106 -> loss.py:64-99): of grad only the rows of the positive cells are written, the objectness gradient
+ * of every cell goes to the workspace's compact plane. y5m_compute_loss_dense_owner_ptrs hands y5m_head_grad_pack_sparse
+ * the planes and the positive-row table of such a workspace (same B / naxs / ny / nx / rows_max). */
+int y5m_compute_loss_dense_sparse(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
+                                  int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
+                                  const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                  float* loss_out, void* ws, size_t ws_bytes, void* stream);
+int y5m_compute_loss_dense_owner_ptrs(void* ws, int B, int naxs, const int* ny, const int* nx, int rows_max,
+                                      int32_t* owner_out[3], float* gobj_out[3], int32_t* bagg_out[3],
+                                      int32_t* count_out[3], int* cap_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Model (model.py): Conv-BN-SiLU building blocks. Activations are (ptr, ld) NHWC, dtype per call.

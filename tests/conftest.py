@@ -37,6 +37,8 @@ _NOT_YET_ON_HARDWARE = {
     "test_dense_targets_builder_matches_dataset_algorithm", "test_sppf_pool_tiled_forms_subprocess",
     "test_hardware_matches_the_executor_probe_table", "test_halo_two_stage_ring_wide_images_subprocess",
     "test_halo_wide_forward_and_dgrad", "test_sparse_head_gradient_pack16_subprocess",
+    # round 6 (GPU still closed to this repository): the fused step on the reference's default loss
+    "test_native_train_step_yolo_loss_matches_autograd", "test_native_train_step_yolo_loss_target_formats_and_dense_gradient",
 }
 
 

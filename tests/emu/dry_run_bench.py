@@ -67,5 +67,5 @@ with emulated():
     # at a tiny size: a Python error in any of them shows here, not in the driver's round-end run
     B_, S_ = os.environ.get("Y5M_DRY_SHAPE", "2x64").split("x")
     sys.argv = ["bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "1", "--leg-iters", "1", "--batch", B_, "--size", S_, "--no-graph",
-                "--fwd-shape", f"{B_}x{S_}", "--detect-shape", f"{B_}x{S_}", "--cpu-shape", f"1x{S_}"]
+                "--fwd-shape", f"{B_}x{S_}", "--detect-shape", f"{B_}x{S_}", "--cpu-shape", f"1x{S_}"] + os.environ.get("Y5M_DRY_ARGS", "").split()      # (e.g. Y5M_DRY_ARGS="--loss yolo --no-detect")
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")

@@ -49,3 +49,13 @@ def test_no_cpu_fallback():
         intersection_over_union(torch.zeros(3, 4), torch.zeros(3, 4))
     with pytest.raises(_lib.Y5MError):
         cells_to_bboxes([torch.zeros(1, 3, 2, 2, 85)] * 3, torch.ones(3, 3, 2), [8, 16, 32], is_pred=True)
+
+
+def test_native_train_step_refuses_a_loss_it_has_no_launch_list_for():
+    """NativeTrainStep enqueues native build-targets + loss launches; it knows the reference's two losses
+    (ComputeLoss, YOLO_LOSS -- train.py:102-106) and refuses anything else by TYPE at construction, before touching a device,
+    instead of failing on a missing attribute inside the first step"""
+    from yolov5m_amd import _lib
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    with pytest.raises(_lib.Y5MError, match="ComputeLoss or YOLO_LOSS"):
+        NativeTrainStep(object(), lambda *a, **k: 0.0)

@@ -304,13 +304,32 @@ def test_eval_plan_packs_once_per_weight_version(monkeypatch):
             return [o.clone() for o in f(x)]
     with emulated():
         x = synth_images(1, 64, 64, seed="ver/img")
+        # default: every forward packs (always correct, whoever wrote the masters) -- also when the FIRST forward of the model runs
+        # under torch.inference_mode() (the flat buffers must not become inference tensors, which have no version counter)
+        m = YOLOV5m(first_out=48, nc=80, anchors=config.ANCHORS, ch=(192, 384, 768))
+        m.load_state_dict(synth_state_dict(), strict=True)
+        m.compute_dtype = "bf16"
+        m.eval()
+        with torch.inference_mode():
+            oi = [o.clone() for o in m(x)]
+            m(x)
+        assert len(packs) == 2 and not m.flat_params.is_inference()
+        with torch.no_grad():
+            m.backbone[0].cbl[0].weight.data.mul_(0.5)              # a writer torch's counters do not see: still picked up
+            assert not torch.equal(m(x)[0], oi[0]) and len(packs) == 3
+        m.pack_once = True
+        with torch.inference_mode():                                 # (the opt-in works under inference_mode too)
+            m(x); m(x)
+        assert len(packs) == 4
+        packs.clear()
         m = _model()
         m.eval()
+        m.pack_once = True                                           # the opt-in: once per weight version
         with torch.no_grad():
             o1 = [o.clone() for o in m(x)]
             n1 = len(packs)
             o2 = [o.clone() for o in m(x)]
-        assert n1 == 1 and len(packs) == 1 and all(torch.equal(a, b) for a, b in zip(o1, o2))
+        assert n1 == 1 and len(packs) == 1 and all(torch.equal(a, b) for a, b in zip(o1, o2)) and all(torch.equal(a, b) for a, b in zip(o1, oi))
         with torch.no_grad():
             m.backbone[0].cbl[0].weight.mul_(0.5)                    # in-place edit of a parameter
             o3 = [o.clone() for o in m(x)]

@@ -1048,6 +1048,91 @@ def test_accumulation_path_sees_a_changed_learning_rate(use_graph):
     assert torch.equal(m.flat_params, p1), float((m.flat_params - p1).abs().max())
 
 
+
+# ---- the reference's DEFAULT loss in the fused step (train.py:102-106 selects YOLO_LOSS unless --ultralytics_loss) ----------
+def _image_boxes(B, n, seed):
+    """the reference's collate_fn target format (dataset.py:199-202): a tuple of per-image float64 arrays (n_i, 5)
+    [cls, x, y, w, h]; image b gets n + b boxes so that the per-image row ranges are ragged"""
+    t = synth_labels(B, n + B, seed=seed).numpy().astype(np.float64)
+    return tuple(t[t[:, 0] == b][: n + b, 1:] for b in range(B))
+
+
+@pytest.mark.parametrize("use_graph,accumulate", [(True, 1), (False, 1), (True, 2)])
+def test_native_train_step_yolo_loss_matches_autograd(use_graph, accumulate):
+    """NativeTrainStep(model, YOLO_LOSS) -- dense targets for the batch in one launch, dense-target loss with the sparse head
+    gradient, the anchor-decay state (bboxes_utils.py:18) advanced INSIDE the captured step -- against the autograd path the
+    reference's train_loop takes (model(x) -> YOLO_LOSS.__call__ -> backward -> clip -> torch Adam), optimizer step for optimizer
+    step: loss values (the same native kernels that g4 / g12 pin against the real reference), the decayed anchors after every
+    step, and the parameter update"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    n_opt = 2
+    xs = [synth_images(2, 64, 64, seed=f"yolo/img{i}").to(DEV) for i in range(n_opt * accumulate)]
+    ts = [_image_boxes(2, 2, f"yolo/lab{i}") for i in range(n_opt * accumulate)]
+    m1 = _model("f32"); m1.train()
+    opt = torch.optim.Adam(m1.parameters(), lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY)
+    lf1 = YOLO_LOSS(m1, rect_training=False)
+    m2 = _model("f32"); m2.train()
+    lf2 = YOLO_LOSS(m2, rect_training=False)
+    step = NativeTrainStep(m2, lf2, nt_max=16, use_graph=use_graph, accumulate=accumulate)
+    assert step.loss_kind == "yolo"
+    k = 0
+    for _ in range(n_opt):
+        p0 = m2.flat_params.clone().cpu().numpy()
+        opt.zero_grad()
+        g_prev = 0.0
+        for _ in range(accumulate):
+            l1 = lf1(m1(xs[k]), ts[k], pred_size=(64, 64))
+            l1.backward()
+            lo = step.step(xs[k], ts[k])
+            np.testing.assert_allclose(float(lo[0]), float(l1.detach()), rtol=2e-5)
+            np.testing.assert_allclose(lo[1:4].cpu().numpy(), lf1.last_components.cpu().numpy(), rtol=2e-5)
+            # the stateful defect of the reference, reproduced on both paths: every box divides the anchors by 640 in place
+            assert torch.equal(lf1.anchors, lf2.anchors)
+            # this micro-batch's gradient: sparse loss gradient + native backward against autograd through the same model
+            g_sum = torch.cat([p.grad.reshape(-1) for p in m1.parameters()]).cpu().numpy().copy()
+            g1, g2 = g_sum - g_prev, m2.flat_grads.cpu().numpy()
+            assert np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max(), (k, np.abs(g1 - g2).max(), np.abs(g1).max())
+            g_prev = g_sum
+            k += 1
+        torch.nn.utils.clip_grad_norm_(m1.parameters(), max_norm=10.0)
+        opt.step()
+        p1t = torch.cat([p.detach().reshape(-1) for p in m1.parameters()])
+        d1, d2 = p1t.cpu().numpy() - p0, m2.flat_params.cpu().numpy() - p0
+        # clip + Adam on equal gradients: the update is +-lr-sized and, on elements whose gradient is at the f32 noise floor of the
+        # two summation orders, its SIGN is noise (see _assert_same_update; this loss leaves more such elements than ComputeLoss)
+        err, ref = np.abs(d1 - d2), np.abs(d1).max()
+        assert ref > 0 and int((err > 2e-2 * ref).sum()) <= 1e-5 * err.size and float(err.max()) <= 0.25 * ref, \
+            (int((err > 2e-2 * ref).sum()), float(err.max()), float(ref))
+        m2.flat_params.copy_(p1t)                                 # both paths start the next step from the same weights
+    assert float(lf2.anchors.abs().max()) < 1e-10              # (5 boxes per batch: the anchors are ~0 after the first one)
+
+
+def test_native_train_step_yolo_loss_target_formats_and_dense_gradient(monkeypatch):
+    """the (nt, 6) [img, cls, x, y, w, h] form of the same boxes (grouped by image) gives the same loss as the per-image arrays;
+    Y5M_SPARSE_HEAD=0 (the dense d loss / d logits + dense head pack) gives the same gradients as the sparse default"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    from yolov5m_amd import _lib
+    x = synth_images(2, 64, 64, seed="yolo/fmt").to(DEV)
+    per = _image_boxes(2, 2, "yolo/fmtlab")
+    flat6 = torch.from_numpy(np.concatenate([np.concatenate([np.full((len(b), 1), i, np.float64), b], 1) for i, b in enumerate(per)], 0))
+    res = []
+    for sparse, tg in (("1", per), ("1", flat6), ("0", per)):
+        monkeypatch.setenv("Y5M_SPARSE_HEAD", sparse)
+        m = _model("f32"); m.train()
+        st = NativeTrainStep(m, YOLO_LOSS(m, rect_training=False), lr=0.0, nt_max=16)
+        lo = st.step(x, tg).cpu().numpy().copy()
+        res.append((lo, m.flat_grads.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], res[2][0])
+    sc = np.abs(res[0][1]).max()                              # (weight gradients are f32 atomic sums: equal up to their order)
+    assert sc > 0 and np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * sc and np.abs(res[0][1] - res[2][1]).max() <= 1e-5 * sc
+    with pytest.raises(_lib.Y5MError, match="grouped by ascending image"):
+        st.step(x, torch.flip(flat6, [0]))
+    with pytest.raises(_lib.Y5MError, match="per-image box arrays"):
+        st.step(x, per[:1])
+
+
 def test_native_optimizer_state_is_torch_adam_state():
     """checkpoint interop (reference utils/utils.py:56-82): after two native steps the exported optimizer state
     loads into torch.optim.Adam and the THIRD step taken by torch equals the third native step; and the

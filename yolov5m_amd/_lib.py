@@ -100,6 +100,7 @@ _SIGS = {
     "y5m_last_error": (ctypes.c_char_p, []),
     "y5m_device_ok": (c_int, []),
     "y5m_persistent_cu_count": (c_int, []),
+    "y5m_r4_kernel_forms": (c_int, []),
     "y5m_decode_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p,
                                  c_int64, c_int64, c_void_p]),
     "y5m_class_obj_accuracy": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
@@ -129,6 +130,11 @@ _SIGS = {
     "y5m_compute_loss_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
                                        c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
                                        c_size_t, c_void_p]),
+    "y5m_compute_loss_dense_sparse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                              c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
+                                              c_size_t, c_void_p]),
+    "y5m_compute_loss_dense_owner_ptrs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_void_p]),
     "y5m_conv_tile_n": (c_int, [c_int]),
     "y5m_conv_is_pointwise": (c_int, [c_void_p, c_int]),
     "y5m_conv_stats_rows": (c_int, [c_void_p, c_int]),

@@ -47,6 +47,9 @@ extern "C" const char* y5m_last_error(void) { return g_err; }
 // workgroups a persistent (one per CU) launch uses: the device's CU count capped by Y5M_PERSIST_CUS (y5m_common.h)
 extern "C" int y5m_persistent_cu_count(void) { return y5m_persistent_cus(); }
 
+// the Y5M_R4_KERNELS mask as the library parsed it (once, atoi & 31: y5m_common.h) -- what the launchers actually dispatch on
+extern "C" int y5m_r4_kernel_forms(void) { return y5m_r4_forms(); }
+
 extern "C" int y5m_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

@@ -510,23 +510,31 @@ extern "C" size_t y5m_compute_loss_dense_workspace_bytes(int B, int naxs, const 
     return dense_tables_bytes(5 * naxs * dense_nt(rows_max, naxs)) + loss_ws_layout(B, naxs, ny, nx, dense_nt(rows_max, naxs), off, nblk) + 256;
 }
 
-extern "C" int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
-                                      int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
-                                      const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
-                                      float* loss_out, void* ws, size_t ws_bytes, void* stream) {
-    if (ws_bytes < y5m_compute_loss_dense_workspace_bytes(B, naxs, ny, nx, rows_max)) { y5m_set_error("loss_dense ws too small"); return Y5M_EWS; }
-    hipStream_t st = y5m_stream(stream);
-    const int nt = dense_nt(rows_max, naxs);
-    const int cap = 5 * naxs * nt;
+// the row tables of the dense loss at the front of its workspace (count / bagg / tbox / anch / tcls per scale); returns the rest
+static char* dense_tables(void* ws, int cap, y5m_targets tg[3]) {
     char* w = reinterpret_cast<char*>(ws);
-    y5m_targets tg[3];
-    BtOut o;
     for (int s = 0; s < 3; ++s) {
         tg[s].count = reinterpret_cast<int32_t*>(w); w += y5m_align(4);
         tg[s].bagg = reinterpret_cast<int32_t*>(w); w += y5m_align((size_t)cap * 16);
         tg[s].tbox = reinterpret_cast<float*>(w); w += y5m_align((size_t)cap * 16);
         tg[s].anch = reinterpret_cast<float*>(w); w += y5m_align((size_t)cap * 8);
         tg[s].tcls = reinterpret_cast<int32_t*>(w); w += y5m_align((size_t)cap * 4);
+    }
+    return w;
+}
+
+static int run_loss_dense(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
+                          int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
+                          const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                          float* loss_out, void* ws, size_t ws_bytes, void* stream, int sparse_grad) {
+    if (ws_bytes < y5m_compute_loss_dense_workspace_bytes(B, naxs, ny, nx, rows_max)) { y5m_set_error("loss_dense ws too small"); return Y5M_EWS; }
+    hipStream_t st = y5m_stream(stream);
+    const int nt = dense_nt(rows_max, naxs);
+    const int cap = 5 * naxs * nt;
+    y5m_targets tg[3];
+    BtOut o;
+    char* w = dense_tables(ws, cap, tg);
+    for (int s = 0; s < 3; ++s) {
         o.count[s] = tg[s].count; o.bagg[s] = tg[s].bagg; o.tbox[s] = tg[s].tbox; o.anch[s] = tg[s].anch; o.tcls[s] = tg[s].tcls;
     }
     hipLaunchKernelGGL(dense_to_rows_kernel, dim3(3), dim3(BT_T), 0, st, dense[0], dense[1], dense[2], anchors, B, naxs,
@@ -534,7 +542,48 @@ extern "C" int y5m_compute_loss_dense(const float* const p[3], float* const grad
     Y5M_CHECK_LAUNCH("dense_to_rows_kernel");
     const size_t used = (size_t)(w - reinterpret_cast<char*>(ws));
     return run_loss(p, grad, dense, B, naxs, ny, nx, nc, tg, nt, balance, lambda_box, lambda_obj, lambda_cls, loss_out, w,
-                    ws_bytes - used, st);
+                    ws_bytes - used, st, sparse_grad);
+}
+
+extern "C" int y5m_compute_loss_dense(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
+                                      int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
+                                      const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                      float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    return run_loss_dense(p, grad, dense, B, naxs, ny, nx, nc, anchors, rows_max, balance, lambda_box, lambda_obj, lambda_cls,
+                          loss_out, ws, ws_bytes, stream, 0);
+}
+
+// The dense-target loss with the SPARSE gradient of y5m_compute_loss_sparse: of grad only the rows of the positive cells are
+// written, the objectness gradient of every cell (ignore cells included: their BCE target stays -1) goes to the compact plane.
+extern "C" int y5m_compute_loss_dense_sparse(const float* const p[3], float* const grad[3], const float* const dense[3], int B,
+                                             int naxs, const int* ny, const int* nx, int nc, const float* anchors, int rows_max,
+                                             const float balance[3], float lambda_box, float lambda_obj, float lambda_cls,
+                                             float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    Y5M_REQUIRE(grad != nullptr, "y5m_compute_loss_dense_sparse is the gradient-producing variant");
+    return run_loss_dense(p, grad, dense, B, naxs, ny, nx, nc, anchors, rows_max, balance, lambda_box, lambda_obj, lambda_cls,
+                          loss_out, ws, ws_bytes, stream, 1);
+}
+
+// what y5m_head_grad_pack_sparse needs of a y5m_compute_loss_dense_sparse workspace: per scale the owner / objectness-gradient
+// planes and the positive-row table (bagg, count); *cap_out = the tables' capacity
+extern "C" int y5m_compute_loss_dense_owner_ptrs(void* ws, int B, int naxs, const int* ny, const int* nx, int rows_max,
+                                                 int32_t* owner_out[3], float* gobj_out[3], int32_t* bagg_out[3],
+                                                 int32_t* count_out[3], int* cap_out) {
+    Y5M_REQUIRE(ws && owner_out && gobj_out && bagg_out && count_out && cap_out, "null");
+    const int nt = dense_nt(rows_max, naxs);
+    const int cap = 5 * naxs * nt;
+    y5m_targets tg[3];
+    char* w = dense_tables(ws, cap, tg);
+    size_t off[3][6]; int nblk[3];
+    loss_ws_layout(B, naxs, ny, nx, nt, off, nblk);
+    for (int s = 0; s < 3; ++s) {
+        owner_out[s] = reinterpret_cast<int32_t*>(w + off[s][0]);
+        gobj_out[s] = reinterpret_cast<float*>(w + off[s][5]);
+        bagg_out[s] = tg[s].bagg;
+        count_out[s] = tg[s].count;
+    }
+    *cap_out = cap;
+    return Y5M_OK;
 }
 
 // =================================================================================================

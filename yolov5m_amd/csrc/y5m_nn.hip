@@ -1132,6 +1132,13 @@ static int pool_tile_cs(int H, int W, int C, int dtype, int bytes_per_item_bf16,
 extern "C" int y5m_sppf_pool_tiled(int H, int W, int C, int dtype);
 template <typename T> __global__ void sppf_pool_tile_kernel(const T* __restrict__ x, int ld, int H, int W, int C8, int CS,
                                                             T* __restrict__ o1, T* __restrict__ o2, T* __restrict__ o3);
+// once per kernel instantiation: raise its dynamic-LDS cap to the largest tile pool_tile_cs admits (150 KB); false (checked on
+// every call, set never again) = the runtime refused, the caller runs the separable kernels instead
+template <auto KERN> static bool pool_tile_ready() {
+    static int ok = -1;
+    if (ok < 0) ok = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10) == hipSuccess ? 1 : 0;
+    return ok == 1;
+}
 extern "C" size_t y5m_sppf_pool_workspace_bytes(int B, int H, int W, int C) { return (size_t)3 * B * H * W * C * 4 + 256; }
 extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, void* o1, void* o2, void* o3, void* ws,
                              size_t ws_bytes, int dtype, void* stream) {
@@ -1144,13 +1151,18 @@ extern "C" int y5m_sppf_pool(const void* x, int ld, int B, int H, int W, int C, 
         const int cs = pool_tile_cs(H, W, C, dtype, 2 * 16, 2 * 32);
         const int slabs = (C / 8 + cs - 1) / cs;
         const size_t lds = (size_t)H * W * cs * (dtype == Y5M_BF16 ? 2 * 16 : 2 * 32);
+        bool launched = false;
         DISPATCH_T(dtype, {
-            auto kern = sppf_pool_tile_kernel<T>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(B * slabs)), dim3(256), lds, st, (const T*)x, ld, H, W, C / 8, cs, (T*)o1, (T*)o2, (T*)o3);
+            if (pool_tile_ready<sppf_pool_tile_kernel<T>>()) {
+                hipLaunchKernelGGL(sppf_pool_tile_kernel<T>, dim3((unsigned)(B * slabs)), dim3(256), lds, st, (const T*)x, ld, H, W, C / 8, cs,
+                                   (T*)o1, (T*)o2, (T*)o3);
+                launched = true;
+            }
         })
-        Y5M_CHECK_LAUNCH("sppf_pool_tile_kernel");
-        return Y5M_OK;
+        if (launched) {
+            Y5M_CHECK_LAUNCH("sppf_pool_tile_kernel");
+            return Y5M_OK;
+        }
     }
     DISPATCH_T(dtype, T* h5 = (T*)ws; T* h9 = h5 + plane; T* h13 = h9 + plane;
                hipLaunchKernelGGL(sppf_rowmax_kernel<T>, dim3(ew_blocks(n)), dim3(EW_T), 0, st, (const T*)x, ld, B, H, W, C / 8, h5, h9, h13);
@@ -1450,14 +1462,18 @@ extern "C" int y5m_sppf_pool_bwd(const void* z0, const void* z1, const void* z2,
         const int slabs = (C / 8 + cs - 1) / cs;
         const size_t lds = (size_t)H * W * cs * (dtype == Y5M_BF16 ? 3 * 16 + 8 : 3 * 32 + 8);
         hipStream_t st = y5m_stream(stream);
+        bool launched = false;
         DISPATCH_T(dtype, {
-            auto kern = sppf_pool_bwd_tile_kernel<T>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(B * slabs)), dim3(256), lds, st, (const T*)z0, (const T*)z1, (const T*)z2, ldz,
-                               (T*)g0, (T*)g1, (T*)g2, (const T*)g3, ldg, H, W, C / 8, cs);
+            if (pool_tile_ready<sppf_pool_bwd_tile_kernel<T>>()) {
+                hipLaunchKernelGGL(sppf_pool_bwd_tile_kernel<T>, dim3((unsigned)(B * slabs)), dim3(256), lds, st, (const T*)z0, (const T*)z1,
+                                   (const T*)z2, ldz, (T*)g0, (T*)g1, (T*)g2, (const T*)g3, ldg, H, W, C / 8, cs);
+                launched = true;
+            }
         })
-        Y5M_CHECK_LAUNCH("sppf_pool_bwd_tile_kernel");
-        return Y5M_OK;
+        if (launched) {
+            Y5M_CHECK_LAUNCH("sppf_pool_bwd_tile_kernel");
+            return Y5M_OK;
+        }
     }
     const void* zs[3] = {z0, z1, z2};
     void* gs[4] = {g0, g1, g2, const_cast<void*>(g3)};

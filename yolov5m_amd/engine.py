@@ -906,8 +906,10 @@ class Engine:
                                                         ldp, _lib.ptr(P["gb"]), dt, st()), "y5m_head_grad_pack")
                 # sparse form (the loss wrote the target rows + a compact objectness plane): one f32 per cell read; dense form: the
                 # whole f32 gradient; either way the bf16 operand rows of the two GEMMs behind it are written in full
-                sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
-                ops.append((_kind(pack, "head_pack", (M * self.naxs * 4 * (1 if sparse else self.nch), M * ldp * self.esz, 0, 4 * N)), ()))
+                # (two figures: which one applies is decided where the launch decides -- `head_owner` set or not -- when the plan is
+                #  asked, algorithmic_bytes below)
+                pack.traffic_sparse = (M * self.naxs * 4, M * ldp * self.esz, 0, 4 * N)
+                ops.append((_kind(pack, "head_pack", (M * self.naxs * 4 * self.nch, M * ldp * self.esz, 0, 4 * N)), ()))
                 wa = WgradArgs()
                 wa.zeros = _lib.zero_page(self.dev).data_ptr()
                 wa.dy, wa.x, wa.dwgt = scratch.data_ptr(), x.ptr, self.gw.data_ptr() + 4 * lay.gw_off
@@ -1233,18 +1235,24 @@ class Engine:
                 e1.record()
                 timeline.append((getattr(fn, "kind", getattr(fn, "__name__", "other")), e0, e1))
 
-    def algorithmic_bytes(self):
+    def algorithmic_bytes(self, sparse_head=None):
         """The plan's ALGORITHMIC HBM traffic: every operand of every launch-list entry moved once (see _traffic), summed per
         list and per kernel family. Returns {"pack" | "forward" | "backward": {"act_read", "act_written", "par_read",
         "par_written", "launches", "by_kind": {kind: [act_read, act_written, par_read, par_written, launches]}}, "B": batch}.
         The act_* bytes are proportional to the batch, the par_* bytes (weights, weight gradients, BatchNorm rows, fills) do
         not depend on it: total(B') = act * B' / B + par. What L2 absorbs or re-reads is NOT in here -- the PMC counters'
-        job (tools/pmc_bench.sh); this is the floor a launch list can be held against."""
+        job (tools/pmc_bench.sh); this is the floor a launch list can be held against. The head-gradient pack is counted in the
+        form its launch would take NOW: sparse once NativeTrainStep's loss has set `head_owner`, dense (85x the read) on a plan
+        driven through autograd (`backward(grads)`)."""
+        if sparse_head is None:                           # (NativeTrainStep.algorithmic_bytes passes the form ITS loss produces)
+            sparse_head = self.head_owner is not None
         out = {"B": self.B}
         for name, lst in (("pack", self.pack), ("forward", self.fwd), ("backward", self.bwd if self.training else [])):
             tot, by = [0, 0, 0, 0, 0], {}
             for fn, _args in lst:
                 t = getattr(fn, "traffic", None)
+                if sparse_head:
+                    t = getattr(fn, "traffic_sparse", t)
                 kind = getattr(fn, "kind", getattr(fn, "__name__", "other"))
                 if t is None:
                     if kind not in ("join", "finalize", "fold_all"):
@@ -1275,12 +1283,13 @@ class Engine:
         buffers (B,naxs,ny,nx,5+nc) f32 -- engine-owned, overwritten by the next forward."""
         if images is not None:
             self.x_in.copy_(images)
-        # Training plans re-pack every step (the masters have just been updated). An INFERENCE plan packs its bf16 weight rows and
-        # folds BatchNorm once per weight version: the pack launch reads all 85 MB of masters and is ~4 % of an eval forward at
-        # B = 32 @ 640x640. The version is torch's own in-place counters of the parameters and the running-statistics buffer
-        # (load_state_dict, optimizers, manual edits all bump them) plus the counter of num_batches_tracked, which every training
-        # forward bumps -- the native optimizer and BatchNorm kernels write through raw pointers and bump nothing themselves.
-        key = None if self.training else self._weights_key()
+        # Every forward packs the bf16 weight rows (and an inference plan folds BatchNorm) from the f32 masters: one launch reading
+        # 85 MB, ~4 % of an eval forward at B = 32 @ 640x640 -- and always correct, whoever wrote the masters (the native optimizer and
+        # BatchNorm kernels write through raw pointers, `dist.broadcast` / `all_reduce` and a fresh `.data` view bump no counter).
+        # OPT-IN (`model.pack_once = True`, or Y5M_PACK_ONCE=1: a deployed detector whose weights are frozen): an inference plan packs
+        # once per weight VERSION -- torch's in-place counters of the parameters and the running-statistics buffers plus
+        # `model.mark_weights_changed()` for the writers those counters do not see.
+        key = self._weights_key() if (not self.training and getattr(self.model, "pack_once", False)) else None
         if key is None or key != getattr(self, "_packed_key", None):
             self._run(self.pack)
             self._packed_key = key
@@ -1291,9 +1300,13 @@ class Engine:
         m = self.model
         # (a Parameter is `p.data = view of the flat buffer`: it keeps its OWN version counter, so every parameter is asked; the
         #  running statistics are plain views of their flat buffer and share its counter; counters only grow, so the sum moves
-        #  whenever any of them does)
-        return (m.flat_params.data_ptr(), sum(p._version for p in m._param_list) + m.flat_params._version,
-                m._flat_stats._version, m._nbt._version, getattr(m, "_weights_epoch", 0))
+        #  whenever any of them does). Inference tensors (buffers created under torch.inference_mode) have no counter: no key,
+        #  pack on every forward.
+        try:
+            return (m.flat_params.data_ptr(), sum(p._version for p in m._param_list) + m.flat_params._version,
+                    m._flat_stats._version, m._nbt._version, getattr(m, "_weights_epoch", 0))
+        except RuntimeError:
+            return None
 
     def backward(self, grads=None):
         """grads: 3 tensors d(loss)/d(logits) (or None if already written into head gout buffers).

@@ -48,6 +48,23 @@ class _DenseLossFn(torch.autograd.Function):
         return None, None, None, g[0] * gout, g[1] * gout, g[2] * gout
 
 
+class _DenseWorkspace:
+    """Device buffers of the dense-target loss for one PLAN of the fused train step (NativeTrainStep with YOLO_LOSS): the dense
+    targets of the 3 scales, the loss workspace (row tables + per-cell planes) and the 4 loss values. A captured graph holds
+    these addresses, so the workspace lives and dies with the plan (Engine._loss_ws)."""
+
+    def __init__(self, device, B, naxs, shapes, rows_max):
+        L = _lib.lib()
+        self.key = ("yolo", B, naxs, tuple(shapes), rows_max)
+        self.ny = _lib.int_array([s[0] for s in shapes])
+        self.nx = _lib.int_array([s[1] for s in shapes])
+        self.dense = [torch.zeros((B, naxs, ny, nx, 6), dtype=torch.float32, device=device) for (ny, nx) in shapes]
+        self.loss_ws_bytes = L.y5m_compute_loss_dense_workspace_bytes(B, naxs, self.ny, self.nx, rows_max)
+        self.loss_ws = torch.empty(self.loss_ws_bytes, dtype=torch.uint8, device=device)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=device)
+        self.owner_ptrs = None
+
+
 class YOLO_LOSS:
     """reference loss.py:20-99"""
 

@@ -291,6 +291,9 @@ class YOLOV5m(nn.Module):
         # native-engine state
         self.compute_dtype = "bf16"        # "bf16" (throughput) | "f32" (parity: exact-f32 MFMA)
         self.static_outputs = False        # True: forward returns the engine's own output buffers
+        # True: an inference plan packs its weights once per weight VERSION instead of on every forward (Engine.forward; frozen
+        # deployed weights -- writers that torch's version counters do not see must call mark_weights_changed())
+        self.pack_once = os.environ.get("Y5M_PACK_ONCE", "0") == "1"
         self.flat_params = None
         self.flat_grads = None
         self.pslices = None
@@ -313,6 +316,12 @@ class YOLOV5m(nn.Module):
         if self._flat_device == dev and self.flat_params is not None:
             return
         _lib.require_cuda_device(dev)
+        # (a first forward under torch.inference_mode() must not turn the flat buffers -- which live as long as the model and are
+        #  trained in place later -- into inference tensors)
+        with torch.inference_mode(False):
+            self._flatten(dev)
+
+    def _flatten(self, dev):
         params = list(self.parameters())
         n = sum(p.numel() for p in params)
         flat = torch.empty(n, dtype=torch.float32, device=dev)
@@ -406,7 +415,8 @@ class YOLOV5m(nn.Module):
             m0 = torch.cuda.memory_allocated(dev)
             eng, retry = None, False
             try:
-                eng = Engine(self, B, H, W, dtype=dt, training=self.training)
+                with torch.inference_mode(False):      # (a plan outlives the inference_mode block that first asked for it)
+                    eng = Engine(self, B, H, W, dtype=dt, training=self.training)
             except torch.OutOfMemoryError:
                 # the estimate was too small (or there was nothing to estimate from). Only NOTE it here: while this handler
                 # runs, the exception's traceback keeps the frames of the failed Engine.__init__ -- and with them the partly
@@ -427,9 +437,10 @@ class YOLOV5m(nn.Module):
         return eng
 
     def mark_weights_changed(self):
-        """Inference plans pack their bf16 weight rows and fold BatchNorm once per weight version, read from torch's in-place
-        counters (Engine._weights_key). Code that writes parameters or running statistics behind torch's back -- a custom kernel
-        through data_ptr(), a write through a fresh `.data` view -- calls this to make the next inference forward pack again."""
+        """With `pack_once` (opt-in; Engine.forward) inference plans pack their bf16 weight rows and fold BatchNorm once per weight
+        version, read from torch's in-place counters (Engine._weights_key). Code that writes parameters or running statistics behind
+        torch's back -- a custom kernel through data_ptr(), a collective (dist.broadcast / all_reduce bump no counter), a write through
+        a fresh `.data` view -- calls this to make the next inference forward pack again. Without `pack_once` every forward packs."""
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
 
     # ------------------------------------------------------------------ reference API

@@ -173,6 +173,7 @@ def broadcast_parameters(model, src=0, group=None):
         dist.broadcast(model.flat_params, src=src, group=group)
         dist.broadcast(model._flat_stats, src=src, group=group)
         dist.broadcast(model._nbt, src=src, group=group)       # BatchNorm2d.num_batches_tracked
+        model.mark_weights_changed()       # (a collective bumps no torch version counter: a pack_once inference plan must pack again)
     else:
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=src, group=group)

@@ -139,6 +139,17 @@ class NativeTrainStep:
         """accumulate: micro-batches per optimizer step (reference train_loop :87-89, `nbs=64 / batch_size`):
         gradients of `accumulate` consecutive step() calls are SUMMED (the loss is already scaled by the batch
         size, ultralytics_loss.py:118) and clip + Adam run on the sum; flush() forces the step at an epoch end."""
+        from ..loss import YOLO_LOSS
+        from ..ultralytics_loss import ComputeLoss
+        # the two losses of the reference (train.py:102-106: YOLO_LOSS unless --ultralytics_loss): each has its own native
+        # build-targets + loss launches; anything else cannot be enqueued into the fused step and is refused HERE, by type
+        if isinstance(loss_fn, ComputeLoss):
+            self.loss_kind = "ultralytics"
+        elif isinstance(loss_fn, YOLO_LOSS):
+            self.loss_kind = "yolo"
+        else:
+            raise _lib.Y5MError(f"NativeTrainStep: loss_fn must be a yolov5m_amd ComputeLoss or YOLO_LOSS, got {type(loss_fn).__name__} "
+                                "(an arbitrary callable has no native launch list; use train_loop, which goes through autograd)")
         self.model, self.loss_fn = model, loss_fn
         self.accumulate = max(int(accumulate), 1)
         self._micro = 0
@@ -161,6 +172,10 @@ class NativeTrainStep:
         self.aws = torch.zeros(self.aws_bytes, dtype=torch.uint8, device=dev)
         self.targets = torch.zeros((nt_max, 6), dtype=torch.float32, device=dev)
         self.d_nt = torch.zeros(1, dtype=torch.int32, device=dev)
+        # YOLO_LOSS: the batch's boxes (reference collate_fn arrays, dataset.py:199-202: float64 [cls, x, y, w, h]) back to back
+        # and the per-image row ranges, in static buffers filled by load_inputs OUTSIDE any capture
+        self.boxes = torch.zeros((nt_max, 5), dtype=torch.float64, device=dev) if self.loss_kind == "yolo" else None
+        self._img_off = {}
         self.loss_out = None
         # captured graphs: one forward+loss+backward graph PER PLAN (keyed by the plan's (B, H, W, dtype, mode) key, held
         # together with a strong reference to the plan: id(plan) can be reused after a plan is freed), one optimizer graph
@@ -171,25 +186,41 @@ class NativeTrainStep:
 
     # forward + build-targets + loss (+ d loss / d logits) + backward: everything before the optimizer
     def _enqueue_fb(self, eng, timeline=None, bwd_upto=None):
+        eng._run(eng.pack, timeline)
+        eng._run(eng.fwd, timeline)
+        loss_ops = self._loss_ops_yolo(eng) if self.loss_kind == "yolo" else self._loss_ops_ultralytics(eng)
+        loss_ops.kind = "loss"
+        eng._run([(loss_ops, ())], timeline)
+        self.loss_out = eng._loss_ws.loss_out
+        eng._run(eng.bwd if bwd_upto is None else eng.bwd[:bwd_upto], timeline)
+        if bwd_upto is not None:
+            eng.join_all()
+
+    def _plan_workspace(self, eng, key, make):
+        """The loss workspace belongs to the PLAN: a captured graph holds its addresses, so one workspace shared by all
+        plans and re-created whenever the shapes change (what this did until round 2) left the graphs of every other
+        resident size replaying on freed memory -- and step() returning another plan's loss tensor -- as soon as
+        multi_scale came back to a size. It is dropped with the plan (Engine.release)."""
+        ws = getattr(eng, "_loss_ws", None)
+        if ws is None or ws.key != key:
+            dev = eng.outs[0].device
+            m0 = torch.cuda.memory_allocated(dev)
+            ws = eng._loss_ws = make(dev)
+            # (the plan cache budgets by Engine.nbytes: the workspace belongs to the plan)
+            eng.nbytes = getattr(eng, "nbytes", 0) + max(torch.cuda.memory_allocated(dev) - m0, 0)
+        return ws
+
+    # ComputeLoss (ultralytics_loss.py:60-120): build-targets + loss (+ d loss / d logits)
+    def _loss_ops_ultralytics(self, eng):
         from ..ultralytics_loss import _Workspace
         L = _lib.lib()
         lf = self.loss_fn
         st = _lib.stream_ptr()
-        eng._run(eng.pack, timeline)
-        eng._run(eng.fwd, timeline)
         outs = eng.outs
         B = eng.B
         shapes = [(o.shape[2], o.shape[3]) for o in outs]
-        # The loss workspace belongs to the PLAN: a captured graph holds its addresses, so one workspace shared by all
-        # plans and re-created whenever the shapes change (what this did until round 2) left the graphs of every other
-        # resident size replaying on freed memory -- and step() returning another plan's loss tensor -- as soon as
-        # multi_scale came back to a size. It is dropped with the plan (Engine.release).
-        ws = getattr(eng, "_loss_ws", None)
-        if ws is None or ws.key != (B, eng.naxs, tuple(shapes), self.nt_max):
-            m0 = torch.cuda.memory_allocated(outs[0].device)
-            ws = eng._loss_ws = _Workspace(outs[0].device, B, eng.naxs, shapes, self.nt_max)
-            # (the plan cache budgets by Engine.nbytes: the workspace belongs to the plan)
-            eng.nbytes = getattr(eng, "nbytes", 0) + max(torch.cuda.memory_allocated(outs[0].device) - m0, 0)
+        ws = self._plan_workspace(eng, (B, eng.naxs, tuple(shapes), self.nt_max),
+                                  lambda dev: _Workspace(dev, B, eng.naxs, shapes, self.nt_max))
         grads = eng.head_grad_buffers()
         sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
         if sparse and getattr(ws, "owner_ptrs", None) is None:
@@ -211,12 +242,47 @@ class NativeTrainStep:
                                           float(lf.lambda_box), float(lf.lambda_obj), float(lf.lambda_class),
                                           _lib.ptr(ws.loss_out), _lib.ptr(ws.loss_ws), ws.loss_ws_bytes, st),
                        "y5m_compute_loss")
-        loss_ops.kind = "loss"
-        eng._run([(loss_ops, ())], timeline)
-        self.loss_out = ws.loss_out
-        eng._run(eng.bwd if bwd_upto is None else eng.bwd[:bwd_upto], timeline)
-        if bwd_upto is not None:
-            eng.join_all()
+        return loss_ops
+
+    # YOLO_LOSS, the reference's DEFAULT loss (train.py:102-106; loss.py:64-99): dense targets for the whole batch in one launch
+    # (loss.py:101-192 is a host loop per image in the reference), then the dense-target loss + d loss / d logits
+    def _loss_ops_yolo(self, eng):
+        from ..loss import _DenseWorkspace
+        L = _lib.lib()
+        lf = self.loss_fn
+        st = _lib.stream_ptr()
+        outs = eng.outs
+        B = eng.B
+        shapes = [(o.shape[2], o.shape[3]) for o in outs]
+        rows_max = max(self.nt_max, 1)                  # positives per scale <= boxes of the batch (one slot per box and scale)
+        ws = self._plan_workspace(eng, ("yolo", B, eng.naxs, tuple(shapes), rows_max),
+                                  lambda dev: _DenseWorkspace(dev, B, eng.naxs, shapes, rows_max))
+        grads = eng.head_grad_buffers()
+        sparse = os.environ.get("Y5M_SPARSE_HEAD", "1") != "0"
+        if sparse and ws.owner_ptrs is None:
+            own, gob, bag, cnt = ((ctypes.c_void_p * 3)() for _ in range(4))
+            cap = ctypes.c_int(0)
+            _lib.check(L.y5m_compute_loss_dense_owner_ptrs(_lib.ptr(ws.loss_ws), B, eng.naxs, ws.ny, ws.nx, rows_max, own, gob, bag,
+                                                           cnt, ctypes.byref(cap)), "y5m_compute_loss_dense_owner_ptrs")
+            ws.owner_ptrs = [(int(own[i]), int(gob[i]), int(bag[i]), int(cnt[i]), cap.value) for i in range(3)]
+        eng.head_owner = ws.owner_ptrs if sparse else None
+        loss_call = L.y5m_compute_loss_dense_sparse if sparse else L.y5m_compute_loss_dense
+        off = self._img_off[B]
+        stride = _lib.int_array([int(v) for v in lf.S])
+        anc = lf._anc                                    # [state read by the launch, state written by it]: same two buffers for every plan
+
+        def loss_ops():
+            _lib.check(L.y5m_yolo_build_targets(_lib.ptr(self.boxes), _lib.ptr(off), B, ws.ny, ws.nx, stride, _lib.ptr(anc[0]),
+                                                _lib.ptr(anc[1]), float(lf.ignore_iou_thresh), _lib.ptr_array(ws.dense), st),
+                       "y5m_yolo_build_targets")
+            # the reference's in-place anchor decay (bboxes_utils.py:18) as device state: YOLO_LOSS.__call__ swaps its two buffers
+            # on the host, which a captured graph cannot replay -- here the new state is copied back (72 bytes, a graph node)
+            anc[0].copy_(anc[1])
+            _lib.check(loss_call(_lib.ptr_array(outs), _lib.ptr_array(grads), _lib.ptr_array(ws.dense), B, eng.naxs, ws.ny, ws.nx,
+                                 lf.nc, _lib.ptr(lf.anchors_d), rows_max, _lib.float_array(lf.balance), float(lf.lambda_box),
+                                 float(lf.lambda_obj), float(lf.lambda_class), _lib.ptr(ws.loss_out), _lib.ptr(ws.loss_ws),
+                                 ws.loss_ws_bytes, st), "y5m_compute_loss_dense")
+        return loss_ops
 
     def _optimizer(self, timeline=None):
         L = _lib.lib()
@@ -246,7 +312,7 @@ class NativeTrainStep:
         Loss (sparse head gradient): one objectness logit per cell read and one objectness gradient written, f32, plus the
         85-float rows of the matched cells (about three per label); optimizer: the gradient once for the norm, then p, g, m, v
         read and p, m, v written, f32."""
-        eb = eng.algorithmic_bytes()
+        eb = eng.algorithmic_bytes(sparse_head=os.environ.get("Y5M_SPARSE_HEAD", "1") != "0")     # (the condition _loss_ops_* launch on)
         scale = (B / eng.B) if B else 1.0
         cells = sum(o.shape[1] * o.shape[2] * o.shape[3] for o in eng.outs) * eng.B
         rows = 3 * self.nt_max
@@ -254,6 +320,9 @@ class NativeTrainStep:
         lists = {k: dict(eb[k]) for k in ("pack", "forward", "backward")}
         lists["loss"] = {"act_read": cells * 4 + rows * 85 * 4, "act_written": cells * 4 + rows * 85 * 4, "par_read": 0, "par_written": 0,
                          "launches": 1, "by_kind": {}}
+        if self.loss_kind == "yolo":                       # + the dense targets (6 floats per cell) written by build-targets, read by the loss
+            lists["loss"]["act_read"] += cells * 24
+            lists["loss"]["act_written"] += cells * 24
         lists["optimizer"] = {"act_read": 0, "act_written": 0, "par_read": 5 * 4 * n, "par_written": 3 * 4 * n, "launches": 2, "by_kind": {}}
         act = sum(v["act_read"] + v["act_written"] for v in lists.values())
         par = sum(v["par_read"] + v["par_written"] for v in lists.values())
@@ -273,6 +342,9 @@ class NativeTrainStep:
         eng = self.model._engine_for(images)
         if images.data_ptr() != eng.x_in.data_ptr():       # a loader that fills input_buffer() directly skips this copy
             eng.x_in.copy_(images, non_blocking=True)
+        if self.loss_kind == "yolo":
+            self._load_boxes(eng.B, targets)
+            return eng
         nt = int(targets.shape[0])
         if nt > self.nt_max:
             raise _lib.Y5MError(f"nt={nt} exceeds nt_max={self.nt_max}")
@@ -280,6 +352,37 @@ class NativeTrainStep:
             self.targets[:nt].copy_(targets.reshape(-1, 6).float(), non_blocking=True)
         self.d_nt.fill_(nt)
         return eng
+
+    def _load_boxes(self, B, targets):
+        """YOLO_LOSS targets -> the static float64 box rows + per-image row ranges. Accepts the reference's collate_fn format
+        (dataset.py:199-202: a tuple of B per-image arrays (n_i, 5) [cls, x, y, w, h]) and, for callers that hold labels the
+        ComputeLoss way, one (nt, 6) array / tensor [img, cls, x, y, w, h] whose rows are grouped by ascending image index
+        (collate_fn_ultra, dataset.py:204-209) -- box ORDER is part of the contract (first come first served, loss.py:160-190)."""
+        import numpy as np
+        if torch.is_tensor(targets) or (isinstance(targets, np.ndarray) and targets.ndim == 2 and targets.shape[1] == 6):
+            t = torch.as_tensor(targets).detach().to("cpu").double().reshape(-1, 6).numpy()
+            img = t[:, 0].astype(np.int64)
+            if img.size and (np.any(np.diff(img) < 0) or img[0] < 0 or img[-1] >= B):
+                raise _lib.Y5MError("YOLO_LOSS targets as one (nt, 6) array must be grouped by ascending image index in [0, B)")
+            counts = np.bincount(img, minlength=B)
+            flat = np.ascontiguousarray(t[:, 1:])
+        else:
+            per = [np.asarray(b, np.float64).reshape(-1, 5) for b in targets]
+            if len(per) != B:
+                raise _lib.Y5MError(f"YOLO_LOSS targets: {len(per)} per-image box arrays for a batch of {B}")
+            counts = np.array([len(b) for b in per], np.int64)
+            flat = np.concatenate(per, 0) if per else np.zeros((0, 5))
+        nt = int(counts.sum())
+        if nt > self.nt_max:
+            raise _lib.Y5MError(f"nt={nt} exceeds nt_max={self.nt_max}")
+        off = np.zeros(B + 1, np.int32)
+        off[1:] = np.cumsum(counts)
+        d_off = self._img_off.get(B)
+        if d_off is None:
+            d_off = self._img_off[B] = torch.zeros(B + 1, dtype=torch.int32, device=self.boxes.device)
+        if nt:
+            self.boxes[:nt].copy_(torch.from_numpy(np.ascontiguousarray(flat)), non_blocking=True)
+        d_off.copy_(torch.from_numpy(off), non_blocking=True)
 
     def input_buffer(self, B, H, W):
         """the engine's static (B,3,H,W) float32 input tensor for this shape: a data loader (or preprocess_u8 with
@@ -591,7 +694,7 @@ class NativeTrainStep:
                     kern.append((buf.value.decode(), ms, 2.0 * d[0].M * d[0].N * d[0].K))
             elif kind == "bwd_pw":
                 a = item[0].bp          # fused pointwise backward: data gradient + weight gradient flops; HBM-bound (bench.py by_class)
-                r4 = (int(os.environ.get("Y5M_R4_KERNELS", "0") or 0) >> 3) & 1       # (the form launch_bp picks: csrc/y5m_common.h)
+                r4 = (L.y5m_r4_kernel_forms() >> 3) & 1                               # (the form launch_bp picks, as the library parsed it)
                 kern.append((f"bwd_pw_kernel<{a.C},{int(bool(a.accumulate or a.res))},{r4}>", ms, 4.0 * a.M * a.N * a.C,
                              float(a.M) * (2 * a.N + (3 if (a.accumulate or a.res) else 2) * a.C) * 2))     # + algorithmic bytes
             elif kind == "wgrad" and getattr(item[0], "wa", None) is not None:
