@@ -269,6 +269,9 @@ typedef struct {
 } y5m_wgrad_args;
 int y5m_wgrad(const y5m_wgrad_args* args, int dtype, void* stream);
 int y5m_wgrad_kernel_name(const y5m_wgrad_args* args, int dtype, char* buf, int n);   /* see y5m_conv_kernel_name */
+/* the launch geometry y5m_wgrad would use, nothing is launched: out = {n tiles, c tiles, tap groups, pixel-range splits, workgroups,
+ * dY channels per block, X channels per block and tap, pixels per LDS chunk} (tools/wgrad_traffic.py: what the tiling re-reads) */
+int y5m_wgrad_geometry(const y5m_wgrad_args* args, int dtype, int32_t out[8]);
 
 /* Fused backward of a pointwise (1x1, stride 1) CBL with N == C in {48, 96, 192} channels, bf16 (csrc/y5m_bwd_pw.hip;
  * reference model.py:12-28 backward): dy = BatchNorm+SiLU backward of (dz, y) is formed in registers and never stored;

@@ -26,7 +26,7 @@ if HERE not in sys.path:
 
 _REC = []                 # stack of op lists being recorded (innermost capture last)
 _QUERY = ("workspace_bytes", "eligible", "kernel_name", "owner_ptrs", "_is_", "tile_n", "stats_rows", "stages_stats", "acc_slots",
-          "fuse_enabled", "persistent_cu", "device_ok", "last_error", "version")
+          "fuse_enabled", "persistent_cu", "device_ok", "last_error", "version", "geometry")
 
 
 class _LibProxy:

@@ -109,3 +109,35 @@ def test_configs4_80x80_stage_dispatch_is_the_documented_gap():
              ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, Y5M_CONV_HALO_NS2="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def _wgrad_geometry(B, Cin, H, W, Cout, k, s):
+    L = _lib.lib()
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    a = WgradArgs()
+    a.zeros = a.dy = a.x = a.dwgt = _PTR
+    a.B, a.Hin, a.Win, a.ldx, a.Hg, a.Wg, a.sy, a.sx = B, H, W, Cin, Ho, Wo, s, s
+    a.th, a.tw, a.dh0, a.dhs, a.dw0, a.dws = k, k, -p, 1, -p, 1
+    a.C, a.N, a.M, a.lddy, a.lddw, a.ksplit = Cin, Cout, B * Ho * Wo, Cout, k * k * Cin, 0
+    g = (ctypes.c_int32 * 8)()
+    _lib.check(L.y5m_wgrad_geometry(ctypes.byref(a), BF16, g), "y5m_wgrad_geometry")
+    return list(g)
+
+
+@pytest.mark.skipif(not _DEFAULT_ENV, reason="a Y5M_CONV* / Y5M_WGRAD* knob is set: the defaults are what is pinned here")
+def test_weight_gradient_launch_geometry_and_the_xcd_deal_it_implies():
+    """y5m_wgrad_geometry (round 6; tools/wgrad_traffic.py reads it): {n tiles, c tiles, tap groups, ranges, workgroups, dY channels per
+    block, X channels per block and tap, pixels per chunk}. Pins the dominant class of the step -- 192 -> 192 3x3 @ 40x40, B = 64: 18
+    blocks per pixel range, 14 ranges, 252 blocks = 31.5 per XCD, so the kernel's 8 contiguous pieces cut inside 7 of the 14 ranges
+    (profiles/r06_wgrad_traffic.txt: 1.38x of the algorithmic bytes get past the XCDs' L2s; NOTES.md round 6) -- and the
+    kernel-row form of the 48-channel layers."""
+    g = _wgrad_geometry(64, 192, 40, 40, 192, 3, 1)
+    assert g == [1, 2, 9, 14, 252, 192, 96, 64], g
+    G = g[0] * g[1] * g[2]
+    q8, r8 = g[4] >> 3, g[4] & 7                              # the kernel's deal: XCD x takes q8 (+ 1 if x < r8) consecutive logical blocks
+    starts = [x * (q8 + 1) if x < r8 else r8 * (q8 + 1) + (x - r8) * q8 for x in range(1, 8)]
+    assert (G, sum(1 for b in starts if b % G != 0)) == (18, 7), starts
+    assert _wgrad_geometry(64, 48, 160, 160, 48, 3, 1)[:5] == [1, 1, 3, 170, 510]       # wgrad_rows_kernel: one kernel row per block
+    g1 = _wgrad_geometry(64, 192, 40, 40, 192, 1, 1)                                    # pointwise: ~224 blocks, 2 per range
+    assert g1[:3] == [1, 2, 1] and g1[3] * 2 == g1[4] == 224

@@ -141,6 +141,7 @@ _SIGS = {
     "y5m_conv_kernel_name": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "y5m_conv_multi_kernel_name": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     "y5m_wgrad_kernel_name": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "y5m_wgrad_geometry": (c_int, [c_void_p, c_int, c_void_p]),
     "y5m_conv_is_halo": (c_int, [c_void_p, c_int]),
     "y5m_conv_stages_stats": (c_int, [c_void_p, c_int]),
     "y5m_conv": (c_int, [c_void_p, c_int, c_void_p]),

@@ -26,6 +26,8 @@
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef y5m_wgrad_args WgradParams;
+// launch geometry of the last y5m_wgrad call of this thread (also filled by a name-only call): y5m_wgrad_geometry
+static thread_local int32_t g_wg_geom[8];
 
 // 4 k-values (pixels 4g+j of a 16-row block) of channel (lane&15) from a [32][16] bf16 sub-tile.
 // Each lane supplies the address of ITS OWN 8-byte piece of the 4x16 block its 16-lane group covers:
@@ -394,6 +396,8 @@ static int launch_wgrad(WgradParams& P, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
+        const int32_t geom[8] = {P.tiles_n, P.tiles_c, taps, P.ksplit, (int32_t)grid, C::TN, C::CBLK, C::KCH};
+        memcpy(g_wg_geom, geom, sizeof(geom));
         Y5M_NAME_ONLY(Y5M_OK, "wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", WN, WC, WK, CFR, TPB, NFR, (int)SB);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, P);
         Y5M_CHECK_LAUNCH("wgrad_kernel");
@@ -699,6 +703,8 @@ static int launch_wgrad_rows_form(WgradParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         attr = true;
     }
+    const int32_t geom[8] = {1, 1, 3, P.ksplit, 3 * P.ksplit, C::N, 48, 32 * WK};       // (one kernel ROW of three taps per block)
+    memcpy(g_wg_geom, geom, sizeof(geom));
     Y5M_NAME_ONLY(Y5M_OK, "wgrad_rows_kernel<%d,%d,%d,%d>", WN, WK, S, (int)R4);
     hipLaunchKernelGGL(kern, dim3((unsigned)(3 * P.ksplit)), dim3(256), C::LDS, st, P, spr, nruns);
     Y5M_CHECK_LAUNCH("wgrad_rows_kernel");
@@ -750,6 +756,19 @@ extern "C" int y5m_wgrad_kernel_name(const y5m_wgrad_args* args, int dtype, char
     y5m_name_only = 0;
     if (rc != Y5M_OK) return rc;
     snprintf(buf, (size_t)n, "%s", y5m_name_buf);
+    return Y5M_OK;
+}
+
+// The launch geometry y5m_wgrad would use for these arguments, nothing is launched: out = {n tiles, c tiles, tap groups (blocks along
+// the tap axis), pixel-range splits, workgroups, dY channels per block, X channels per block and tap, pixels per LDS chunk}.
+// Logical block order = ((range * n_tiles + n) * c_tiles + c) * tap_groups + tap, dealt to the XCDs in 8 contiguous pieces.
+extern "C" int y5m_wgrad_geometry(const y5m_wgrad_args* args, int dtype, int32_t out[8]) {
+    Y5M_REQUIRE(out != nullptr, "out");
+    y5m_name_only = 1;
+    const int rc = y5m_wgrad(args, dtype, nullptr);
+    y5m_name_only = 0;
+    if (rc != Y5M_OK) return rc;
+    memcpy(out, g_wg_geom, sizeof(g_wg_geom));
     return Y5M_OK;
 }
 

@@ -76,7 +76,7 @@ class YOLO_LOSS:
         self.balance = [4.0, 1.0, 0.4]                                                # :36
         self.nc = model.head.nc
         self.anchors_d = model.head.anchors.clone().detach().contiguous()             # :39
-        # :40 `self.anchors` (decays in place!): device-resident state, two buffers (the kernel reads one, writes the other)
+        # :40 `self.anchors` (decays in place!): device-resident state, two buffers (the kernel reads [0] and writes [1]; [1] is copied back)
         self._anc = [self.anchors_d.clone().float().contiguous(), torch.zeros_like(self.anchors_d, dtype=torch.float32)]
         self.na = self.anchors_d.reshape(9, 2).shape[0]
         self.num_anchors_per_scale = self.na // 3
@@ -116,8 +116,9 @@ class YOLO_LOSS:
         _lib.check(L.y5m_yolo_build_targets(_lib.ptr(d_boxes), _lib.ptr(d_off), B, ny, nx, st, _lib.ptr(self._anc[0]),
                                             _lib.ptr(self._anc[1]), float(self.ignore_iou_thresh), _lib.ptr_array(dense),
                                             _lib.stream_ptr()), "y5m_yolo_build_targets")
-        if off[-1]:
-            self._anc.reverse()                       # the state after this call
+        # the state after this call goes back into _anc[0] (72 bytes, same stream): _anc[0] is ALWAYS the state buffer, so a captured
+        # NativeTrainStep graph of this loss object (which holds both addresses) and eager calls of __call__ can be mixed freely
+        self._anc[0].copy_(self._anc[1])
         self._keep = (d_boxes, d_off)                 # until the launch has run
         return dense
 
