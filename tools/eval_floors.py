@@ -57,7 +57,10 @@ def plan_rows(Bp, S, B):
             fl, key = 0.0, (kind,)
             if kind == "conv_igemm" and d and isinstance(d[0], _lib.ConvArgs):
                 a = d[0]
-                L.y5m_conv_kernel_name(ctypes.byref(a), e.dtype, buf, 192)
+                q = type(a)()                              # the dispatch depends on the launch size: ask for the REPORTED batch, not the plan's
+                ctypes.memmove(ctypes.byref(q), ctypes.byref(a), ctypes.sizeof(a))
+                q.B, q.M = int(a.B * sc), int(a.M * sc)
+                _lib.check(L.y5m_conv_kernel_name(ctypes.byref(q), e.dtype, buf, 192), "y5m_conv_kernel_name")
                 fl = 2.0 * a.M * a.N * a.K * sc
                 key = (buf.value.decode(), int(a.M * sc), a.N, a.K, f"{a.th}x{a.tw}", a.sy)
             r = rows.setdefault(key, [0, 0.0, 0.0])
