@@ -86,3 +86,35 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
     assert opt2.state_dict()["param_groups"][0]["lr"] == 1e-3
     s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
     assert len(s1) == len(s2) and all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
+
+
+def test_yolo_loss_target_staging_ragged_empty_and_grouped_forms():
+    """NativeTrainStep._load_boxes (host logic of the fused step on YOLO_LOSS; reference collate_fn, dataset.py:199-202): per-image
+    arrays with EMPTY images, the (nt, 6) grouped form with images that have no row, zero boxes in the whole batch, and the
+    refusals (too many boxes, wrong image count, rows not grouped by image)"""
+    import numpy as np
+    from yolov5m_amd import _lib
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    st = object.__new__(NativeTrainStep)                       # (the constructor needs a device; the staging logic does not)
+    st.nt_max, st._img_off = 6, {}
+    st.boxes = torch.zeros((6, 5), dtype=torch.float64)
+    a = np.array([[3, .5, .5, .2, .2], [7, .1, .2, .3, .4]])
+    b = np.array([[1, .9, .8, .1, .1]])
+    st._load_boxes(4, (a, np.zeros((0, 5)), b, np.zeros((0, 5))))
+    assert st._img_off[4].tolist() == [0, 2, 2, 3, 3]
+    assert np.array_equal(st.boxes[:3].numpy(), np.concatenate([a, b]))
+    flat = torch.tensor([[0, 3, .5, .5, .2, .2], [0, 7, .1, .2, .3, .4], [2, 1, .9, .8, .1, .1]], dtype=torch.float32)
+    st.boxes.zero_()
+    st._load_boxes(4, flat)
+    assert st._img_off[4].tolist() == [0, 2, 2, 3, 3]
+    assert np.allclose(st.boxes[:3].numpy(), np.concatenate([a, b]), atol=1e-7)
+    st._load_boxes(2, (np.zeros((0, 5)), np.zeros((0, 5))))     # no box at all: every range empty (the loss is then NaN, loss.py:212)
+    assert st._img_off[2].tolist() == [0, 0, 0] and st._img_off[4].tolist() == [0, 2, 2, 3, 3]      # one offset buffer per batch size
+    with pytest.raises(_lib.Y5MError, match="exceeds nt_max"):
+        st._load_boxes(1, (np.zeros((7, 5)),))
+    with pytest.raises(_lib.Y5MError, match="per-image box arrays"):
+        st._load_boxes(3, (a, b))
+    with pytest.raises(_lib.Y5MError, match="grouped by ascending image"):
+        st._load_boxes(4, flat[[2, 0, 1]])
+    with pytest.raises(_lib.Y5MError, match="grouped by ascending image"):
+        st._load_boxes(2, flat)                                 # image index 2 in a batch of 2
