@@ -1067,7 +1067,7 @@ def test_native_train_step_yolo_loss_matches_autograd(use_graph, accumulate):
     from yolov5m_amd.loss import YOLO_LOSS
     from yolov5m_amd.utils.training_utils import NativeTrainStep
     n_opt = 2
-    xs = [synth_images(2, 64, 64, seed=f"yolo/img{i}").to(DEV) for i in range(n_opt * accumulate)]
+    xs = [synth_images(2, 32, 64, seed=f"yolo/img{i}").to(DEV) for i in range(n_opt * accumulate)]
     ts = [_image_boxes(2, 2, f"yolo/lab{i}") for i in range(n_opt * accumulate)]
     m1 = _model("f32"); m1.train()
     opt = torch.optim.Adam(m1.parameters(), lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY)
@@ -1082,7 +1082,7 @@ def test_native_train_step_yolo_loss_matches_autograd(use_graph, accumulate):
         opt.zero_grad()
         g_prev = 0.0
         for _ in range(accumulate):
-            l1 = lf1(m1(xs[k]), ts[k], pred_size=(64, 64))
+            l1 = lf1(m1(xs[k]), ts[k], pred_size=(32, 64))
             l1.backward()
             lo = step.step(xs[k], ts[k])
             np.testing.assert_allclose(float(lo[0]), float(l1.detach()), rtol=2e-5)
@@ -1110,18 +1110,21 @@ def test_native_train_step_yolo_loss_matches_autograd(use_graph, accumulate):
 
 def test_native_train_step_yolo_loss_target_formats_and_dense_gradient(monkeypatch):
     """the (nt, 6) [img, cls, x, y, w, h] form of the same boxes (grouped by image) gives the same loss as the per-image arrays;
-    Y5M_SPARSE_HEAD=0 (the dense d loss / d logits + dense head pack) gives the same gradients as the sparse default"""
+    Y5M_SPARSE_HEAD=0 (the dense d loss / d logits + dense head pack) gives the same gradients as the sparse default. One model,
+    lr = 0, the loss object's anchor state put back to its initial value before every step (it decays with every box)"""
     from yolov5m_amd.loss import YOLO_LOSS
     from yolov5m_amd.utils.training_utils import NativeTrainStep
     from yolov5m_amd import _lib
-    x = synth_images(2, 64, 64, seed="yolo/fmt").to(DEV)
+    x = synth_images(2, 32, 64, seed="yolo/fmt").to(DEV)
     per = _image_boxes(2, 2, "yolo/fmtlab")
     flat6 = torch.from_numpy(np.concatenate([np.concatenate([np.full((len(b), 1), i, np.float64), b], 1) for i, b in enumerate(per)], 0))
+    m = _model("f32"); m.train()
+    lf = YOLO_LOSS(m, rect_training=False)
+    st = NativeTrainStep(m, lf, lr=0.0, nt_max=16)
     res = []
     for sparse, tg in (("1", per), ("1", flat6), ("0", per)):
         monkeypatch.setenv("Y5M_SPARSE_HEAD", sparse)
-        m = _model("f32"); m.train()
-        st = NativeTrainStep(m, YOLO_LOSS(m, rect_training=False), lr=0.0, nt_max=16)
+        lf._anc[0].copy_(lf.anchors_d)
         lo = st.step(x, tg).cpu().numpy().copy()
         res.append((lo, m.flat_grads.cpu().numpy().copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], res[2][0])
