@@ -1108,6 +1108,29 @@ def test_native_train_step_yolo_loss_matches_autograd(use_graph, accumulate):
     assert float(lf2.anchors.abs().max()) < 1e-10              # (5 boxes per batch: the anchors are ~0 after the first one)
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 128), (3, 32, 64)])
+def test_native_train_step_yolo_loss_vs_oracle(shape):
+    """the fused step's YOLO_LOSS value (f32) against the ORACLE's restatement of loss.py:64-246 (oracle/loss_ref.YoloLossRef: the
+    per-image Python loop of build_targets incl. the in-place anchor decay, compute_loss per scale) evaluated on the oracle's own
+    train-mode logits: north_star tolerance 1e-4 on the loss; and the state the loss object is left in. (tools/shape_fuzz_emu.py runs
+    the same comparison on the CPU executor at eight odd shapes: 9e-8 .. 3e-7, profiles/r06_shape_fuzz_emu.txt)"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    B, H, W = shape
+    x = synth_images(B, H, W, seed="yolo/oracle")
+    per = _image_boxes(B, 2, "yolo/oraclelab")
+    sd = synth_state_dict()
+    ref = loss_ref.YoloLossRef(sd["head.anchors"])
+    with torch.no_grad():
+        lr_ = float(ref(model_ref.forward(sd, x, training=True), per))
+    m = _model("f32"); m.train()
+    lf = YOLO_LOSS(m, rect_training=False)
+    step = NativeTrainStep(m, lf, lr=0.0, nt_max=32)
+    lo = step.step(x.to(DEV), per)
+    np.testing.assert_allclose(float(lo[0]), lr_, rtol=1e-4)
+    assert torch.equal(lf.anchors, ref.anchors)
+
+
 def test_native_train_step_yolo_loss_target_formats_and_dense_gradient(monkeypatch):
     """the (nt, 6) [img, cls, x, y, w, h] form of the same boxes (grouped by image) gives the same loss as the per-image arrays;
     Y5M_SPARSE_HEAD=0 (the dense d loss / d logits + dense head pack) gives the same gradients as the sparse default. One model,
