@@ -1277,3 +1277,38 @@ def test_train_loop_mirror_runs_both_input_paths():
     # whole tightly and the single worst element loosely
     assert float((d0 - d1).norm()) <= 1e-4 * float(d0.norm())
     assert float((d0 - d1).abs().max()) <= 1e-2 * float(d0.abs().max())
+
+
+@pytest.mark.parametrize("loss_kind", ["ultralytics", "yolo"])
+def test_train_loop_with_fused_step_matches_autograd_loop(loss_kind):
+    """train_loop(optim = NativeTrainStep(...)): the reference's epoch (utils/training_utils.py:81-132: accumulation to the nominal
+    batch 64, the forced step on the last batch, the uint8 input stage) with every batch as one fused native step, against the same
+    epoch through autograd + torch.optim.Adam -- for both losses of train.py:102-106: mean loss and the epoch's parameter update"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep, train_loop
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(3):
+        img = torch.randint(0, 256, (2, 3, 64, 96), generator=g, dtype=torch.uint8)
+        lab = synth_labels(2, 3, seed=f"tlf{i}")
+        if loss_kind == "yolo":
+            t = lab.numpy().astype(np.float64)
+            lab = tuple(t[t[:, 0] == b][:, 1:] for b in range(2))
+        batches.append((img, lab))
+    mk = (lambda m: YOLO_LOSS(m, rect_training=False)) if loss_kind == "yolo" else (lambda m: ComputeLoss(m))
+    m1 = _model("f32"); m1.train()
+    opt = torch.optim.Adam(m1.parameters(), lr=config.LEARNING_RATE, weight_decay=config.WEIGHT_DECAY)
+    mean1 = train_loop(m1, batches, opt, mk(m1), multi_scale_training=False)
+    m2 = _model("f32"); m2.train()
+    lf2 = mk(m2)
+    step = NativeTrainStep(m2, lf2, nt_max=16, use_graph=True)
+    p0 = m2.flat_params.clone().cpu().numpy()
+    mean2 = train_loop(m2, batches, step, lf2, multi_scale_training=False)
+    assert step.accumulate == 32 and int(step.d_step.item()) == 1            # batch 2 -> one forced optimizer step at the epoch's end
+    np.testing.assert_allclose(mean2, mean1, rtol=2e-5)
+    d1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu().numpy() - p0
+    d2 = m2.flat_params.cpu().numpy() - p0
+    err, ref = np.abs(d1 - d2), np.abs(d1).max()
+    assert ref > 0 and int((err > 2e-2 * ref).sum()) <= 1e-5 * err.size and float(err.max()) <= 0.25 * ref, \
+        (int((err > 2e-2 * ref).sum()), float(err.max()), float(ref))

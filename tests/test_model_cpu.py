@@ -118,3 +118,52 @@ def test_yolo_loss_target_staging_ragged_empty_and_grouped_forms():
         st._load_boxes(4, flat[[2, 0, 1]])
     with pytest.raises(_lib.Y5MError, match="grouped by ascending image"):
         st._load_boxes(2, flat)                                 # image index 2 in a batch of 2
+
+
+def test_train_loop_drives_a_fused_step_like_the_reference_loop():
+    """train_loop(optim = NativeTrainStep): control flow only (a recording stand-in for the step; the real one is the GPU suite's
+    test_train_loop_with_fused_step_matches_autograd_loop): accumulate = round(64 / batch) set on the step, every batch stepped once,
+    one flush at the epoch's end (reference utils/training_utils.py:87-89, :116), uint8 batches resized straight into the step's input
+    buffer, float batches divided by 255, the mean of the returned loss values; a step built for another model / loss is refused"""
+    from unittest import mock
+    from yolov5m_amd import _lib
+    from yolov5m_amd.utils import training_utils as T
+
+    class Rec(T.NativeTrainStep):
+        def __init__(self, model, loss_fn):
+            self.model, self.loss_fn, self.calls, self.accumulate = model, loss_fn, [], 1
+            self.bufs = {}
+
+        def set_accumulate(self, k):
+            self.calls.append(("accumulate", k))
+
+        def input_buffer(self, B, H, W):
+            return self.bufs.setdefault((B, H, W), torch.zeros((B, 3, H, W)))
+
+        def step(self, images, targets):
+            self.calls.append(("step", tuple(images.shape), float(images.max()), images.data_ptr() in {b.data_ptr() for b in self.bufs.values()}))
+            return torch.tensor([float(len([c for c in self.calls if c[0] == "step"])), 0, 0, 0])
+
+        def flush(self):
+            self.calls.append(("flush",))
+
+    class M:
+        flat_params = torch.zeros(1)
+    m, lf = M(), object()
+
+    def fake_pre(u8, hw, out=None):                              # (the native kernel needs a device: here the same arithmetic in torch)
+        out.copy_(torch.nn.functional.interpolate(u8.float() / 255, size=hw, mode="bilinear", align_corners=False))
+        return out
+    u8 = [(torch.full((4, 3, 64, 96), 255, dtype=torch.uint8), None) for _ in range(3)]
+    with mock.patch.object(T, "preprocess_u8", fake_pre):
+        st = Rec(m, lf)
+        mean = T.train_loop(m, u8, st, lf, multi_scale_training=False)
+    assert st.calls[0] == ("accumulate", 16) and st.calls[-1] == ("flush",)
+    steps = [c for c in st.calls if c[0] == "step"]
+    assert len(steps) == 3 and all(c[1] == (4, 3, 64, 96) and abs(c[2] - 1.0) < 1e-6 and c[3] for c in steps)
+    assert abs(mean - (1 + 2 + 3) / 3) < 1e-6
+    st = Rec(m, lf)
+    T.train_loop(m, [(torch.full((64, 3, 32, 32), 51.0), None)], st, lf, multi_scale_training=False)
+    assert st.calls[0] == ("accumulate", 1) and abs(st.calls[1][2] - 0.2) < 1e-6 and not st.calls[1][3]
+    with pytest.raises(_lib.Y5MError, match="another model"):
+        T.train_loop(M(), u8, st, lf)

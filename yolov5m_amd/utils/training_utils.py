@@ -94,7 +94,12 @@ def preprocess_u8(images_u8, out_hw=None, out=None):
 
 
 def train_loop(model, loader, optim, loss_fn, scaler=None, epoch=0, num_epochs=1, multi_scale_training=True):
-    """reference utils/training_utils.py:81-132 (tqdm/printing dropped; returns the mean loss)."""
+    """reference utils/training_utils.py:81-132 (tqdm/printing dropped; returns the mean loss).
+    `optim` is what train.py:61 builds -- a torch optimizer: autograd through the native model + loss, then optim.step() -- or a
+    NativeTrainStep(model, loss_fn, ...): the same epoch (same accumulation rule, same forced step on the last batch, same input
+    stage) with every batch as ONE fused native step (forward + build-targets + loss + backward [+ clip + Adam] as captured graphs)."""
+    if isinstance(optim, NativeTrainStep):
+        return _train_loop_fused(model, loader, optim, loss_fn, epoch, multi_scale_training)
     nbs = 64                                                   # :87 nominal batch size
     batch_size = len(next(iter(loader))[0])                    # :88
     accumulate = max(round(nbs / batch_size), 1)               # :89
@@ -122,6 +127,35 @@ def train_loop(model, loader, optim, loss_fn, scaler=None, epoch=0, num_epochs=1
             optim.zero_grad(set_to_none=True)
             last_opt_step = idx
     return loss_epoch / max(nb, 1)
+
+
+def _train_loop_fused(model, loader, step, loss_fn, epoch, multi_scale_training):
+    """train_loop with a NativeTrainStep in the optimizer's place. Accumulation: the reference steps when `idx - last_opt_step >=
+    accumulate` (:116, last_opt_step = -1 at the start of every epoch) or on the epoch's last batch, i.e. after every `accumulate`-th
+    micro-batch plus one forced step at the end: NativeTrainStep(accumulate=k) + flush(). The mean loss is summed on the device and
+    read once (the reference reads loss.item() every batch: a host sync per step)."""
+    if step.model is not model or step.loss_fn is not loss_fn:
+        raise _lib.Y5MError("train_loop: the NativeTrainStep passed as `optim` was built for another model / loss object")
+    nbs = 64                                                   # :87
+    batch_size = len(next(iter(loader))[0])                    # :88
+    step.set_accumulate(max(round(nbs / batch_size), 1))       # :89
+    dev = model.flat_params.device
+    loss_sum, nb = None, len(loader)
+    for idx, (images, bboxes) in enumerate(loader):
+        if images.dtype == torch.uint8:
+            # :98-102 on the device, straight into the plan's static input buffer: no further copy of the batch in step()
+            h, w = images.shape[2:4]
+            hw = multi_scale_size(h, w, 640, 32) if multi_scale_training else (h, w)
+            images = preprocess_u8(images.to(dev, non_blocking=True), hw, out=step.input_buffer(images.shape[0], *hw))
+        else:
+            images = images.float() / 255                      # :98
+            if multi_scale_training:
+                images = multi_scale(images, target_shape=640, max_stride=32)
+            images = images.to(dev, non_blocking=True)         # :102
+        lo = step.step(images, bboxes)                         # :107-121
+        loss_sum = lo[0].clone() if loss_sum is None else loss_sum.add_(lo[0])
+    step.flush()                                               # `idx == nb - 1`
+    return float(loss_sum) / max(nb, 1) if loss_sum is not None else 0.0
 
 
 class NativeTrainStep:
@@ -157,6 +191,7 @@ class NativeTrainStep:
         self.lr, self.wd, self.max_norm, self.betas, self.eps = lr, weight_decay, max_norm, betas, eps
         self.nt_max = nt_max
         self.use_graph = use_graph
+        self._overlap_req = overlap
         self.overlap = overlap and accumulate == 1          # bucketed exchange under the backward pass (grad_hook with .launch/.wait)
         self.grad_hook = grad_hook
         model.train()
@@ -547,6 +582,19 @@ class NativeTrainStep:
             eng._pending.clear()
         finally:
             eng.overlap = saved
+
+    def set_accumulate(self, k):
+        """change the number of micro-batches per optimizer step (train_loop derives it from the loader's batch size, :87-89). A
+        pending partial accumulation is stepped first; the captured graphs go (the accumulating graph adds into `gacc`)."""
+        k = max(int(k), 1)
+        if k == self.accumulate:
+            return
+        self.flush()
+        self.accumulate, self._micro = k, 0
+        self.overlap = self._overlap_req and k == 1
+        n = self.model.flat_params.numel()
+        self.gacc = torch.zeros(n, dtype=torch.float32, device=self.model.flat_params.device) if k > 1 else None
+        self._fb_graphs, self._opt_graph = {}, None
 
     def _step_accumulate(self, eng):
         """micro-batch: forward/backward (+ graph replay) then gacc += grads; every `accumulate`-th call the
