@@ -120,7 +120,7 @@ def test_yolo_loss_target_staging_ragged_empty_and_grouped_forms():
         st._load_boxes(2, flat)                                 # image index 2 in a batch of 2
 
 
-def test_train_loop_drives_a_fused_step_like_the_reference_loop():
+def test_train_loop_drives_a_fused_step_like_the_reference_loop(tmp_path, monkeypatch):
     """train_loop(optim = NativeTrainStep): control flow only (a recording stand-in for the step; the real one is the GPU suite's
     test_train_loop_with_fused_step_matches_autograd_loop): accumulate = round(64 / batch) set on the step, every batch stepped once,
     one flush at the epoch's end (reference utils/training_utils.py:87-89, :116), uint8 batches resized straight into the step's input
@@ -167,3 +167,14 @@ def test_train_loop_drives_a_fused_step_like_the_reference_loop():
     assert st.calls[0] == ("accumulate", 1) and abs(st.calls[1][2] - 0.2) < 1e-6 and not st.calls[1][3]
     with pytest.raises(_lib.Y5MError, match="another model"):
         T.train_loop(M(), u8, st, lf)
+    # the loss objects' csv line (every 100th batch; loss.py:82-90) is written by the fused loop too
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "train_eval_metrics" / "run7").mkdir(parents=True)
+
+    class LF:
+        save_logs, filename = True, "run7"
+    lf2 = LF()
+    st = Rec(m, lf2)
+    with mock.patch.object(T, "preprocess_u8", fake_pre):
+        T.train_loop(m, u8, st, lf2, epoch=4, multi_scale_training=False)
+    assert (tmp_path / "train_eval_metrics" / "run7" / "loss.csv").read_text().strip() == "4,0,0.0,0.0,0.0"

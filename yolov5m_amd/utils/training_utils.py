@@ -154,6 +154,12 @@ def _train_loop_fused(model, loader, step, loss_fn, epoch, multi_scale_training)
             images = images.to(dev, non_blocking=True)         # :102
         lo = step.step(images, bboxes)                         # :107-121
         loss_sum = lo[0].clone() if loss_sum is None else loss_sum.add_(lo[0])
+        if getattr(loss_fn, "save_logs", False) and idx % 100 == 0:
+            # the loss objects' own log line (ultralytics_loss.py:108-116, loss.py:82-90): [epoch, batch, box, object, class] every
+            # 100th batch -- the fused step does not go through loss_fn.__call__, so it is written here (one host read per 100 batches)
+            import csv
+            with open(os.path.join("train_eval_metrics", loss_fn.filename, "loss.csv"), "a") as f:
+                csv.writer(f).writerow([epoch, idx] + lo[1:4].tolist())
     step.flush()                                               # `idx == nb - 1`
     return float(loss_sum) / max(nb, 1) if loss_sum is not None else 0.0
 
