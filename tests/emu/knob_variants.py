@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-VARIANTS = ["", "Y5M_R4_KERNELS=31", "Y5M_POOL_TILE=1", "Y5M_HEAD_PACK16=1", "Y5M_CONV_HALO_NS2=1", "Y5M_BWD_PW=0", "Y5M_BWD_PW_MIN_M=0", "Y5M_BWD_STEM=0", "Y5M_LAZY_RES=0", "Y5M_MERGE_C3=0", "Y5M_WGRAD_DIRECT=0",
+VARIANTS = ["", "Y5M_R4_KERNELS=31 Y5M_POOL_TILE=1 Y5M_HEAD_PACK16=1 Y5M_CONV_HALO_NS2=1 Y5M_PACK_ONCE=1",     # (every staged, never-timed variant at once)
+            "Y5M_R4_KERNELS=31", "Y5M_POOL_TILE=1", "Y5M_HEAD_PACK16=1", "Y5M_CONV_HALO_NS2=1", "Y5M_BWD_PW=0", "Y5M_BWD_PW_MIN_M=0", "Y5M_BWD_STEM=0", "Y5M_LAZY_RES=0", "Y5M_MERGE_C3=0", "Y5M_WGRAD_DIRECT=0",
             "Y5M_WGRAD_ROWS=0", "Y5M_WGRAD_AFTER_DGRAD=0", "Y5M_SLOTS=2", "Y5M_SPARSE_HEAD=0", "Y5M_BN_FUSE=0", "Y5M_CONV_HALO=0",
             "Y5M_CONV_GEMM8=0", "Y5M_CONV_GEMM8=1", "Y5M_CONV_PW=0", "Y5M_CONV_MULTI=0"]
 CHILD = r'''
@@ -32,12 +33,12 @@ if __name__ == "__main__":
     bad = 0
     for v in VARIANTS:
         env = dict(os.environ)
-        if v:
-            k, val = v.split("=")
+        for kv in v.split():
+            k, val = kv.split("=")
             env[k] = val
         r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=1800)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         ok = r.returncode == 0 and line
         bad += 0 if ok else 1
-        print(f"{v or '(default)':28s} {'ok  ' + line[0][7:] if ok else 'FAIL ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200]}", flush=True)
+        print(f"{v or '(default)':40s} {'ok  ' + line[0][7:] if ok else 'FAIL ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200]}", flush=True)
     sys.exit(1 if bad else 0)

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("Y5M_BWD_PW_MIN_M", str(200000 * 2 // 64))
 import torch  # noqa: E402
 from emu.harness import emulated  # noqa: E402
-from yolov5m_amd import config  # noqa: E402
+from yolov5m_amd import _lib, config  # noqa: E402
 from yolov5m_amd.model import YOLOV5m  # noqa: E402
 from yolov5m_amd.ultralytics_loss import ComputeLoss  # noqa: E402
 from yolov5m_amd.utils.training_utils import NativeTrainStep  # noqa: E402
@@ -62,6 +62,34 @@ with emulated():
             ta += alg
             print(f"{names:100s} {meas:17.3f} {alg:12.3f} {meas / max(alg, 1e-9):6.2f}")
         print(f"{'sum of the rows above':100s} {tm:17.3f} {ta:12.3f} {tm / ta:6.2f}")
+        # the conv family split by the kernel each launch dispatches to at B = 64 (y5m_conv_kernel_name on the rescaled arguments):
+        # which conv kernel re-reads most (round 6)
+        import ctypes
+        import re
+        L = _lib.lib()
+        buf = ctypes.create_string_buffer(192)
+        byk = {}
+        for lst in (eng.fwd, eng.bwd):
+            for fn, _ in lst:
+                d = getattr(fn, "__defaults__", None)
+                if getattr(fn, "kind", None) != "conv_igemm" or not d:
+                    continue
+                t = fn.traffic
+                by = (t[0] + t[1]) * 64 / B + t[2] + t[3]
+                if hasattr(d[0], "_length_"):
+                    name = "conv_igemm_multi_kernel"
+                else:
+                    q = type(d[0])()
+                    ctypes.memmove(ctypes.byref(q), ctypes.byref(d[0]), ctypes.sizeof(q))
+                    q.B, q.M = q.B * 64 // B, q.M * 64 // B
+                    _lib.check(L.y5m_conv_kernel_name(ctypes.byref(q), eng.dtype, buf, 192), "y5m_conv_kernel_name")
+                    name = re.sub(r"<.*", "", buf.value.decode())
+                e = byk.setdefault(name, [0.0, 0])
+                e[0] += by; e[1] += 1
+        print(f"\n{'conv + data-gradient launches by kernel (PMC name)':60s} {'launches':>8s} {'measured GB/step':>17s} {'algorithmic':>12s} {'ratio':>6s}")
+        for name, (by, n) in sorted(byk.items(), key=lambda kv: -kv[1][0]):
+            meas = pmc[name]["hbm_bytes_per_launch"] * pmc[name]["launches"] / steps / 1e9 if name in pmc else float("nan")
+            print(f"{name:60s} {n:8d} {meas:17.3f} {by / 1e9:12.3f} {meas / (by / 1e9):6.2f}")
     # forward BatchNorm + SiLU passes (read y, write z: 4 B per element) whose output is read ONLY by 1x1 convolutions (+ their weight
     # gradients): the passes a consumer-side "normalise in the loader" fusion could drop -- each needs the loader change in every
     # kernel that reads the tensor (conv_pw / conv_gemm8 forward, wgrad_kernel or bwd_pw_kernel backward)
