@@ -1312,3 +1312,34 @@ def test_train_loop_with_fused_step_matches_autograd_loop(loss_kind):
     err, ref = np.abs(d1 - d2), np.abs(d1).max()
     assert ref > 0 and int((err > 2e-2 * ref).sum()) <= 1e-5 * err.size and float(err.max()) <= 0.25 * ref, \
         (int((err > 2e-2 * ref).sum()), float(err.max()), float(ref))
+
+
+def test_detect_driver_is_the_reference_detect_flow():
+    """yolov5m_amd.detect.detect = the intended flow of the reference's detect.py:46-54 (uint8 HWC image(s) -> CHW -> / 255 -> eval
+    forward -> cells_to_bboxes(is_pred=True) -> non_max_suppression): decode against the oracle's forward + decode (1e-4), the kept
+    rows bit-exact against the oracle's NMS AT THE NMS BOUNDARY (the same decoded (B, N, 6) tensor fed to both), one HWC
+    image = entry 0 of the batch, the model's train / eval state restored, sizes that are not multiples of 32 refused"""
+    from yolov5m_amd import _lib
+    from yolov5m_amd.detect import detect
+    from yolov5m_amd.utils.plot_utils import cells_to_bboxes
+    g = torch.Generator().manual_seed(11)
+    u8 = torch.randint(0, 256, (2, 64, 96, 3), generator=g, dtype=torch.uint8)          # (B, H, W, 3): the PIL / numpy layout
+    m = _model("f32"); m.train()
+    rows = detect(m, u8.numpy(), iou_threshold=0.6, threshold=0.01)
+    assert m.training and len(rows) == 2 and all(0 < len(r) <= 300 for r in rows)
+    x = u8.permute(0, 3, 1, 2).float() / 255
+    m.eval()
+    with torch.no_grad():
+        boxes = cells_to_bboxes(m(x.to(DEV)), m.head.anchors, m.head.stride, is_pred=True, to_list=False)
+        ref_boxes = loss_ref.cells_to_bboxes(model_ref.forward(synth_state_dict(), x, training=False), m.head.anchors.cpu(), m.head.stride, is_pred=True)
+    b = boxes.cpu().numpy()
+    rb = ref_boxes.numpy() if torch.is_tensor(ref_boxes) else np.asarray(ref_boxes, np.float32)
+    assert np.array_equal(b[..., 0], rb[..., 0]) or (b[..., 0] != rb[..., 0]).mean() < 1e-3       # class index (argmax ties aside)
+    assert np.abs(b[..., 1:] - rb[..., 1:]).max() <= 1e-4 * np.abs(rb[..., 1:]).max()
+    kept = loss_ref.non_max_suppression(boxes.cpu(), 0.6, 0.01, 300)
+    for i in range(2):
+        assert np.array_equal(np.asarray(rows[i], np.float32), kept[i][0].astype(np.float32)), i
+    one = detect(m, u8[0].numpy(), iou_threshold=0.6, threshold=0.01)
+    assert len(one) == 1 and one[0] == rows[0] and not m.training
+    with pytest.raises(_lib.Y5MError, match="multiple of 32"):
+        detect(m, torch.zeros((1, 3, 60, 64), dtype=torch.uint8))
