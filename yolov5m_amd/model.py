@@ -19,7 +19,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib, config
+from . import _lib
 from .arch import cbl_list
 
 

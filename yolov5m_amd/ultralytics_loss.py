@@ -5,7 +5,6 @@ analytic backward are four launches (y5m_compute_loss); autograd sees a single F
 backward just scales the gradients the forward already produced.
 """
 import csv
-import ctypes
 import os
 
 import torch
