@@ -515,6 +515,33 @@ def g7_large_step(model):
     save("g7_large_step", **out)
 
 
+def g16_yolo_train_steps(model):
+    """The reference's DEFAULT recipe at the model level (train.py:102-106: YOLO_LOSS): its own train-mode forward on the synthetic
+    weights + a FRESH YOLO_LOSS object over a pinned sequence of two calls (the anchors decay in place with every box) on
+    two batches of 2 x 96 x 128 with ragged box counts; no optimizer step in between (the weights stay the synthetic ones, so the
+    sequence isolates the loss object's state). Stored: inputs (boxes), loss per call, anchors after each call. Pins the fused
+    NativeTrainStep(model, YOLO_LOSS) against the real reference (tests/test_gpu_model.py::test_native_yolo_steps_reference_golden)."""
+    sd = synth_state_dict()
+    model.load_state_dict(sd, strict=True)
+    model.train(True)
+    lf = R.YOLO_LOSS(model, rect_training=False)
+    B, H, W = 2, 96, 128
+    out = {"shape": np.array([B, H, W]), "anchors_start": lf.anchors.clone().numpy()}
+    for call in range(2):
+        x = synth_images(B, H, W, seed=f"g16/img{call}")
+        t = synth_labels(B, 4, seed=f"g16/lab{call}").numpy().astype(np.float64)
+        boxes = tuple(t[t[:, 0] == b][: 2 + b + call, 1:].copy() for b in range(B))       # 2 + 3, then 3 + 4 boxes
+        with torch.no_grad():
+            o = model(x.clone())
+            loss = lf(o, boxes, pred_size=(H, W))
+        out[f"{call}/loss"] = np.array(float(loss))
+        out[f"{call}/anchors_after"] = lf.anchors.clone().numpy()
+        for b in range(B):
+            out[f"{call}/boxes{b}"] = boxes[b]
+    # (running statistics moved by the two train-mode forwards: not part of the fixture; the native step is run with lr = 0)
+    save("g16_yolo_train_steps", **out)
+
+
 def g8_input_stage():
     """reference input stage (utils/training_utils.py:98-100): images.float()/255 then multi_scale with a pinned
     `random` seed: the chosen sizes for several seeds, and sampled output values for two of them"""
@@ -700,7 +727,7 @@ def g12_yolo_build_targets(model):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g16"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -717,4 +744,5 @@ if __name__ == "__main__":
     if "g12" in which: g12_yolo_build_targets(model)
     if "g13" in which: g13_fp64_and_full_gradients(model)
     if "g14" in which: g14_nms_crosspin()
+    if "g16" in which: g16_yolo_train_steps(model)
     if "g15" in which: g15_full_size_backward(model)        # (not in the default list: ~10 min and ~25 GB of host memory)

@@ -65,7 +65,8 @@ SELECT = {
         # (sparse native gradient against the dense autograd one is part of it; the target-format twin is GPU-only: its host logic
         #  is tests/test_model_cpu.py::test_yolo_loss_target_staging_ragged_empty_and_grouped_forms)
         "test_native_train_step_yolo_loss_matches_autograd": lambda kw: kw["use_graph"] and kw["accumulate"] == 1,
-        "test_native_train_step_yolo_loss_vs_oracle": lambda kw: kw["shape"] == (3, 32, 64),
+        "test_native_train_step_yolo_loss_vs_oracle": None,      # (GPU-only: the oracle is pinned by g16, the native step by the next line)
+        "test_native_yolo_steps_reference_golden": lambda kw: True,
         "test_detect_driver_is_the_reference_detect_flow": lambda kw: True,
         # (test_native_train_step_matches_torch_adam / test_input_stage_u8_golden bound rounding-level noise -- 8 near-cancelling
         #  Adam elements of 21 M, 2e-6 absolute -- that the host's un-contracted arithmetic moves: 12 elements / 2.1e-6 here)

@@ -1108,6 +1108,26 @@ def test_native_train_step_yolo_loss_matches_autograd(use_graph, accumulate):
     assert float(lf2.anchors.abs().max()) < 1e-10              # (5 boxes per batch: the anchors are ~0 after the first one)
 
 
+def test_native_yolo_steps_reference_golden(golden):
+    """the fused step on the reference's default loss against the REAL reference (tests/golden/g16_yolo_train_steps.npz, made by
+    tests/golden/make_golden.py from /root/reference): its train-mode forward + a fresh YOLO_LOSS over a pinned two-call sequence
+    (2 + 3, then 3 + 4 boxes on two 2 x 96 x 128 batches; weights fixed: lr = 0 here) -- loss within the north_star's 1e-4, the loss
+    object's decayed anchors bit for bit after every call, the second step through the captured graph"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    from yolov5m_amd.utils.training_utils import NativeTrainStep
+    g = golden("g16_yolo_train_steps")
+    B, H, W = [int(v) for v in g["shape"]]
+    m = _model("f32"); m.train()
+    lf = YOLO_LOSS(m, rect_training=False)
+    assert np.array_equal(lf.anchors.numpy(), g["anchors_start"])
+    step = NativeTrainStep(m, lf, lr=0.0, nt_max=16, use_graph=True)
+    for call in (0, 1):                                     # (call 0 = eager warm-up + capture, call 1 = the replayed graph)
+        x = synth_images(B, H, W, seed=f"g16/img{call}").to(DEV)
+        lo = step.step(x, tuple(g[f"{call}/boxes{b}"] for b in range(B)))
+        np.testing.assert_allclose(float(lo[0]), float(g[f"{call}/loss"]), rtol=1e-4)
+        assert np.array_equal(lf.anchors.numpy(), g[f"{call}/anchors_after"]), call
+
+
 @pytest.mark.parametrize("shape", [(2, 96, 128), (3, 32, 64)])
 def test_native_train_step_yolo_loss_vs_oracle(shape):
     """the fused step's YOLO_LOSS value (f32) against the ORACLE's restatement of loss.py:64-246 (oracle/loss_ref.YoloLossRef: the

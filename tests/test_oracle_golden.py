@@ -259,3 +259,21 @@ def test_g7_large_batch_first_step(golden):
             assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (i, np.abs(got - ref).max())
         loss, _ = loss_ref.compute_loss_ultra(o, torch.from_numpy(g["targets"]), sd["head.anchors"])
     np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+
+
+def test_g16_yolo_loss_model_level_sequence(golden):
+    """the REAL reference's train-mode forward + a fresh YOLO_LOSS over a pinned two-call sequence at the model level (g16): the
+    oracle's restatements (model_ref.forward + loss_ref.YoloLossRef) give the same loss values (1e-5) and the same decayed anchors
+    (bit for bit) after every call"""
+    g = golden("g16_yolo_train_steps")
+    B, H, W = [int(v) for v in g["shape"]]
+    sd = synth_state_dict()
+    ref = loss_ref.YoloLossRef(sd["head.anchors"])
+    assert np.array_equal(ref.anchors.numpy(), g["anchors_start"])
+    for call in range(2):
+        x = synth_images(B, H, W, seed=f"g16/img{call}")
+        boxes = tuple(g[f"{call}/boxes{b}"] for b in range(B))
+        with torch.no_grad():
+            l = ref(model_ref.forward(sd, x, training=True), boxes)
+        np.testing.assert_allclose(float(l), float(g[f"{call}/loss"]), rtol=1e-5)
+        assert np.array_equal(ref.anchors.numpy(), g[f"{call}/anchors_after"])
