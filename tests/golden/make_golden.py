@@ -542,6 +542,49 @@ def g16_yolo_train_steps(model):
     save("g16_yolo_train_steps", **out)
 
 
+def g17_train_loop_epoch(model):
+    """The REAL reference's train_loop (utils/training_utils.py:81-132) for one epoch on this CPU -- 3 uint8 batches of 2 x 64 x 96,
+    multi_scale off, Adam(lr, weight_decay) as train.py:61 builds it, GradScaler / autocast inert on a CPU -- for both losses of
+    train.py:102-106: batch 2 -> accumulate = 32 -> ONE forced optimizer step on the last batch (clip 10, Adam with L2 decay) on
+    the gradients of the three batches. Stored: the batches, every batch's loss value, and the epoch's parameter update at 8192 strided
+    positions (+ its absolute sum). Pins train_loop's mechanics -- with a torch optimizer AND with the fused NativeTrainStep in its
+    place -- against the real thing (tests/test_gpu_model.py::test_train_loop_epoch_reference_golden)."""
+    import contextlib
+    import io
+    from utils.training_utils import train_loop as ref_train_loop          # the reference's (oracle.ref_import put it on sys.path)
+    g = torch.Generator().manual_seed(17)
+    imgs = [torch.randint(0, 256, (2, 3, 64, 96), generator=g, dtype=torch.uint8) for _ in range(3)]
+    labs = [synth_labels(2, 3, seed=f"g17/lab{i}") for i in range(3)]
+    out = {"images": torch.stack(imgs).numpy(), "labels": torch.stack(labs).numpy(),
+           "lr": np.array(R.config.LEARNING_RATE), "weight_decay": np.array(R.config.WEIGHT_DECAY)}
+    for kind in ("ultralytics", "yolo"):
+        model.load_state_dict(synth_state_dict(), strict=True)
+        model.train(True)
+        p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+        opt = torch.optim.Adam(model.parameters(), lr=R.config.LEARNING_RATE, weight_decay=R.config.WEIGHT_DECAY)
+        lf = R.ComputeLoss(model) if kind == "ultralytics" else R.YOLO_LOSS(model, rect_training=False)
+        losses = []
+
+        def rec(*a, _lf=lf, **k):
+            l = _lf(*a, **k)
+            losses.append(float(l))
+            return l
+        if kind == "ultralytics":
+            loader = list(zip(imgs, labs))
+        else:
+            loader = [(im, tuple(lb.numpy().astype(np.float64)[lb[:, 0] == b][:, 1:] for b in range(2))) for im, lb in zip(imgs, labs)]
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ref_train_loop(model, loader, opt, rec, torch.cuda.amp.GradScaler(), 0, 1, multi_scale_training=False)
+        d = torch.cat([p.detach().reshape(-1) for p in model.parameters()]) - p0
+        step = d.numel() // 8192
+        out[f"{kind}/losses"] = np.array(losses)
+        out[f"{kind}/update_sample"] = d[::step][:8192].numpy().copy()
+        out[f"{kind}/update_step"] = np.array(step)
+        out[f"{kind}/update_abs_sum"] = np.array(float(d.double().abs().sum()))
+        print(kind, losses, float(d.abs().max()))
+    save("g17_train_loop_epoch", **out)
+
+
 def g8_input_stage():
     """reference input stage (utils/training_utils.py:98-100): images.float()/255 then multi_scale with a pinned
     `random` seed: the chosen sizes for several seeds, and sampled output values for two of them"""
@@ -727,7 +770,7 @@ def g12_yolo_build_targets(model):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g16", "g17"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -745,4 +788,5 @@ if __name__ == "__main__":
     if "g13" in which: g13_fp64_and_full_gradients(model)
     if "g14" in which: g14_nms_crosspin()
     if "g16" in which: g16_yolo_train_steps(model)
+    if "g17" in which: g17_train_loop_epoch(model)
     if "g15" in which: g15_full_size_backward(model)        # (not in the default list: ~10 min and ~25 GB of host memory)

@@ -64,7 +64,9 @@ SELECT = {
         # the fused step on the reference's default loss: the captured form (the anchor state advances inside the recording)
         # (sparse native gradient against the dense autograd one is part of it; the target-format twin is GPU-only: its host logic
         #  is tests/test_model_cpu.py::test_yolo_loss_target_staging_ragged_empty_and_grouped_forms)
-        "test_native_train_step_yolo_loss_matches_autograd": lambda kw: kw["use_graph"] and kw["accumulate"] == 1,
+        "test_native_train_step_yolo_loss_matches_autograd": None,      # (ran green here as a one-off, profiles/r06_emu_extra.txt; the suite
+        #  holds the fused YOLO_LOSS step against the REAL reference instead: g16 below, and g17 = the reference's train_loop epoch)
+        "test_train_loop_epoch_reference_golden": lambda kw: (kw["loss_kind"], kw["optimizer"]) == ("yolo", "fused"),
         "test_native_train_step_yolo_loss_vs_oracle": None,      # (GPU-only: the oracle is pinned by g16, the native step by the next line)
         "test_native_yolo_steps_reference_golden": lambda kw: True,
         "test_detect_driver_is_the_reference_detect_flow": lambda kw: True,
