@@ -585,6 +585,57 @@ def g17_train_loop_epoch(model):
     save("g17_train_loop_epoch", **out)
 
 
+def g18_train_loop_accumulation(model):
+    """The REAL reference's train_loop with SEVERAL optimizer steps in the epoch: 7 uint8 batches of 22 x 32 x 32 -> accumulate =
+    round(64 / 22) = 3 -> steps after batches 3 and 6 (`idx - last_opt_step >= accumulate`, :116) and the forced one on batch 7 alone;
+    ComputeLoss. Stored: batches, per-batch losses, the parameter update at 8192 strided positions + its absolute sum, how many times
+    optim.step ran -- and the reference's OWN sensitivity: the same epoch from weights perturbed by 1e-7 / 1e-6 relative (one f32 ulp /
+    ten) moves that update by 2.4 % / 3.9 % in relative L2 (train-mode BatchNorm over 22 samples at 1 x 1, three Adam steps): the
+    yardstick an implementation with another summation order is held to. Pins the accumulation rule of train_loop."""
+    import contextlib
+    import io
+    from utils.training_utils import train_loop as ref_train_loop
+    g = torch.Generator().manual_seed(18)
+    nb, B = 7, 22
+    imgs = [torch.randint(0, 256, (B, 3, 32, 32), generator=g, dtype=torch.uint8) for _ in range(nb)]
+    labs = [synth_labels(B, 2, seed=f"g18/lab{i}") for i in range(nb)]
+    loader = list(zip(imgs, labs))
+
+    def epoch(eps):
+        sd = synth_state_dict()
+        if eps:
+            gen = torch.Generator().manual_seed(1)
+            sd = {k: (v * (1 + eps * torch.randn(v.shape, generator=gen)) if v.is_floating_point() and "anchors" not in k else v) for k, v in sd.items()}
+        model.load_state_dict(sd, strict=True)
+        model.train(True)
+        p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+        opt = torch.optim.Adam(model.parameters(), lr=R.config.LEARNING_RATE, weight_decay=R.config.WEIGHT_DECAY)
+        steps, losses = [], []
+        real_step = opt.step
+        opt.step = lambda *a, **k: (steps.append(1), real_step(*a, **k))[1]
+        lf = R.ComputeLoss(model)
+
+        def rec(*a, **k):
+            l = lf(*a, **k)
+            losses.append(float(l))
+            return l
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ref_train_loop(model, loader, opt, rec, torch.cuda.amp.GradScaler(), 0, 1, multi_scale_training=False)
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()]) - p0, losses, len(steps)
+    d, losses, nsteps = epoch(0.0)
+    step = d.numel() // 8192
+    ref = d[::step][:8192].numpy().copy()
+    sens = {}
+    for eps in (1e-7, 1e-6):
+        dp = epoch(eps)[0][::step][:8192].numpy()
+        sens[eps] = float(np.linalg.norm(dp - ref) / np.linalg.norm(ref))
+    print("optimizer steps", nsteps, "losses", losses, "max |update|", float(d.abs().max()), "sensitivity", sens)
+    save("g18_train_loop_accumulation", images=torch.stack(imgs).numpy(), labels=torch.stack(labs).numpy(), losses=np.array(losses),
+         optimizer_steps=np.array(nsteps), update_sample=ref, update_step=np.array(step),
+         update_abs_sum=np.array(float(d.double().abs().sum())), lr=np.array(R.config.LEARNING_RATE), weight_decay=np.array(R.config.WEIGHT_DECAY),
+         update_rel_l2_weights_1e7=np.array(sens[1e-7]), update_rel_l2_weights_1e6=np.array(sens[1e-6]))
+
+
 def g8_input_stage():
     """reference input stage (utils/training_utils.py:98-100): images.float()/255 then multi_scale with a pinned
     `random` seed: the chosen sizes for several seeds, and sampled output values for two of them"""
@@ -770,7 +821,7 @@ def g12_yolo_build_targets(model):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g16", "g17", "g18"]
     torch.manual_seed(0)
     model = ref_model()
     if "g1" in which: g1_giou()
@@ -789,4 +840,5 @@ if __name__ == "__main__":
     if "g14" in which: g14_nms_crosspin()
     if "g16" in which: g16_yolo_train_steps(model)
     if "g17" in which: g17_train_loop_epoch(model)
+    if "g18" in which: g18_train_loop_accumulation(model)
     if "g15" in which: g15_full_size_backward(model)        # (not in the default list: ~10 min and ~25 GB of host memory)

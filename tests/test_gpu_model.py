@@ -1410,3 +1410,48 @@ def test_train_loop_epoch_reference_golden(golden, loss_kind, optimizer):
     # lr, every element within 2 lr (a flipped sign), and the update's absolute sum (above) within 1e-3
     err, lr_ = np.abs(got - ref), float(g["lr"])
     assert int((err > 2e-2 * lr_).sum()) <= 16 and float(err.max()) <= 2.1 * lr_, (int((err > 2e-2 * lr_).sum()), float(err.max()))
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "fused"])
+def test_train_loop_accumulation_reference_golden(golden, optimizer):
+    """train_loop's accumulation rule against the REAL reference's loop (tests/golden/g18_train_loop_accumulation.npz): 7 uint8 batches
+    of 22 x 32 x 32 -> accumulate = round(64 / 22) = 3 -> optimizer steps after batches 3 and 6 and the forced one on batch 7 alone
+    (utils/training_utils.py:87-89, :116) = three clip + Adam steps. Per-batch losses (they feel every earlier step), the number of
+    optimizer steps, and the epoch's parameter update; with a torch optimizer and with the fused NativeTrainStep in its place"""
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    from yolov5m_amd.utils.training_utils import NativeTrainStep, train_loop
+    g = golden("g18_train_loop_accumulation")
+    loader = list(zip(torch.from_numpy(g["images"]), torch.from_numpy(g["labels"])))
+    m = _model("f32"); m.train()
+    p0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().clone()
+    lf = ComputeLoss(m)
+    ref_losses, lr_ = g["losses"], float(g["lr"])
+    if optimizer == "torch":
+        seen, nsteps = [], []
+
+        def rec(*a, **k):
+            l = lf(*a, **k)
+            seen.append(float(l.detach()))
+            return l
+        opt = torch.optim.Adam(m.parameters(), lr=lr_, weight_decay=float(g["weight_decay"]))
+        real = opt.step
+        opt.step = lambda *a, **k: (nsteps.append(1), real(*a, **k))[1]
+        mean = train_loop(m, loader, opt, rec, multi_scale_training=False)
+        assert len(nsteps) == int(g["optimizer_steps"]) == 3
+        np.testing.assert_allclose(seen, ref_losses, rtol=2e-4)
+    else:
+        step = NativeTrainStep(m, lf, lr=lr_, weight_decay=float(g["weight_decay"]), nt_max=64, use_graph=True)
+        mean = train_loop(m, loader, step, lf, multi_scale_training=False)
+        assert step.accumulate == 3 and int(step.d_step.item()) == int(g["optimizer_steps"]) == 3
+    np.testing.assert_allclose(mean, ref_losses.mean(), rtol=2e-4)
+    d = (torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu() - p0).numpy()
+    np.testing.assert_allclose(np.abs(d.astype(np.float64)).sum(), float(g["update_abs_sum"]), rtol=2e-3)
+    # Element by element this update is NOT a property of an implementation: the reference's own epoch, started from weights perturbed by
+    # 1e-7 relative (one f32 ulp), moves it by 2.4 % in relative L2 and a third of its elements by more than 2 % of lr (train-mode
+    # BatchNorm over 22 samples at 1 x 1, three Adam steps; the perturbed runs are part of the fixture). Calibrated bound: no further from
+    # the reference than twice its own one-ulp sensitivity (CPU executor: 2.6 %, the same through autograd and the fused step)
+    got, ref = d[::int(g["update_step"])][:8192], g["update_sample"]
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print(f"update: rel L2 {rel:.4f}; the reference's own sensitivity to 1e-7 / 1e-6 weight perturbations: "
+          f"{float(g['update_rel_l2_weights_1e7']):.4f} / {float(g['update_rel_l2_weights_1e6']):.4f}")
+    assert rel <= 2.0 * float(g["update_rel_l2_weights_1e7"]), (rel, float(g["update_rel_l2_weights_1e7"]))
