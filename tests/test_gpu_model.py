@@ -1407,7 +1407,9 @@ def test_train_loop_epoch_reference_golden(golden, loss_kind, optimizer):
     # Adam's FIRST step is -lr g / (|g| + 1e-8) per element: where the clipped gradient + weight decay nearly cancels, its sign is decided
     # by the last bits of a sum the reference's CPU kernels and these kernels order differently (1e-4 relative) -- 6-7 of the 8192 sampled
     # elements on the CPU executor, the same ones through autograd and through the fused step. So: 99.8 % of the sample within 2 % of
-    # lr, every element within 2 lr (a flipped sign), and the update's absolute sum (above) within 1e-3
+    # lr, every element within 2 lr (a flipped sign), and the update's absolute sum (above) within 1e-3. Calibration (tools: the same
+    # epoch of the REAL reference from weights perturbed by 1e-7 / 1e-6 relative): 4-5 / 9-13 of these 8192 elements move by more than
+    # 2 % of lr, up to 1.99 lr -- the bound of 16 is the reference's own sensitivity to a ten-ulp perturbation
     err, lr_ = np.abs(got - ref), float(g["lr"])
     assert int((err > 2e-2 * lr_).sum()) <= 16 and float(err.max()) <= 2.1 * lr_, (int((err > 2e-2 * lr_).sum()), float(err.max()))
 
