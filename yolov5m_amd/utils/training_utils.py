@@ -133,7 +133,7 @@ def _train_loop_fused(model, loader, step, loss_fn, epoch, multi_scale_training)
     """train_loop with a NativeTrainStep in the optimizer's place. Accumulation: the reference steps when `idx - last_opt_step >=
     accumulate` (:116, last_opt_step = -1 at the start of every epoch) or on the epoch's last batch, i.e. after every `accumulate`-th
     micro-batch plus one forced step at the end: NativeTrainStep(accumulate=k) + flush(). The mean loss is summed on the device and
-    read once (the reference reads loss.item() every batch: a host sync per step)."""
+    read once at the epoch's end (the reference reads it every 10th batch for its progress bar, :124-127)."""
     if step.model is not model or step.loss_fn is not loss_fn:
         raise _lib.Y5MError("train_loop: the NativeTrainStep passed as `optim` was built for another model / loss object")
     nbs = 64                                                   # :87
