@@ -42,6 +42,7 @@ _NOT_YET_ON_HARDWARE = {
     "test_native_train_step_yolo_loss_vs_oracle", "test_train_loop_with_fused_step_matches_autograd_loop",
     "test_detect_driver_is_the_reference_detect_flow", "test_native_yolo_steps_reference_golden",
     "test_train_loop_epoch_reference_golden", "test_train_loop_accumulation_reference_golden",
+    "test_train_driver_checkpoints_and_resume",
 }
 
 

@@ -2,6 +2,8 @@
 gradients, and the fused native train step (clip + Adam), against the golden vectors produced by the real
 reference and against the CPU oracle. f32 mode: north_star tolerance 1e-4 rel on logits and loss;
 bf16 mode: stated looser tolerance (bf16 activations, f32 accumulation)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1457,3 +1459,35 @@ def test_train_loop_accumulation_reference_golden(golden, optimizer):
     print(f"update: rel L2 {rel:.4f}; the reference's own sensitivity to 1e-7 / 1e-6 weight perturbations: "
           f"{float(g['update_rel_l2_weights_1e7']):.4f} / {float(g['update_rel_l2_weights_1e6']):.4f}")
     assert rel <= 2.0 * float(g["update_rel_l2_weights_1e7"]), (rel, float(g["update_rel_l2_weights_1e7"]))
+
+
+def test_train_driver_checkpoints_and_resume(tmp_path, monkeypatch):
+    """yolov5m_amd.train.train = the reference's train.py:56-140 flow (loaders handed in): run naming model_<n>, one checkpoint per
+    epoch in the reference's {"state_dict", "optimizer"} layout, resume from the last one (model + Adam state through the fused step's
+    torch.optim.Adam-compatible state_dict) landing where the uninterrupted run lands; default loss = YOLO_LOSS (train.py:102-106)"""
+    from yolov5m_amd.loss import YOLO_LOSS
+    from yolov5m_amd.train import SyntheticLoader, train
+    from yolov5m_amd.ultralytics_loss import ComputeLoss
+    monkeypatch.chdir(tmp_path)
+    p_init = torch.cat([p.detach().reshape(-1) for p in _model("f32").parameters()]).cpu()
+    # default loss, two epochs, fused step
+    ld = SyntheticLoader(2, 2, 64, ultralytics_loss=False, boxes_per_image=3)
+    m, opt, losses = train(ld, epochs=2, rect=True, dtype="f32", nt_max=16, model=_model("f32"), checkpoint_root="CK")
+    assert isinstance(opt.loss_fn, YOLO_LOSS) and len(losses) == 2 and all(np.isfinite(losses))
+    assert sorted(os.listdir("CK/model_1")) == ["checkpoint_epoch_1.pth.tar", "checkpoint_epoch_2.pth.tar"]
+    ck = torch.load("CK/model_1/checkpoint_epoch_2.pth.tar", map_location="cpu", weights_only=True)
+    assert set(ck) == {"state_dict", "optimizer"} and len(ck["state_dict"]) == 481 and ck["optimizer"]["param_groups"][0]["lr"] == config.LEARNING_RATE
+    assert int(opt.d_step.item()) == 2                                   # batch 2 -> accumulate 32 -> one forced step per epoch
+    # ComputeLoss: 1 epoch + resume for 1 more == 2 epochs uninterrupted
+    lu = SyntheticLoader(2, 2, 64, ultralytics_loss=True, boxes_per_image=3)
+    mB, oB, _ = train(lu, epochs=2, ultralytics_loss=True, rect=True, dtype="f32", nt_max=16, model=_model("f32"), checkpoint_root="CKB")
+    assert isinstance(oB.loss_fn, ComputeLoss)
+    train(lu, epochs=1, ultralytics_loss=True, rect=True, dtype="f32", nt_max=16, model=_model("f32"), checkpoint_root="CKA")
+    mA, oA, _ = train(lu, epochs=1, ultralytics_loss=True, rect=True, dtype="f32", nt_max=16, model=_model("f32"), checkpoint_root="CKA",
+                      resume=True, filename="model_1")
+    assert sorted(os.listdir("CKA/model_1")) == ["checkpoint_epoch_1.pth.tar", "checkpoint_epoch_2.pth.tar"] and int(oA.d_step.item()) == 2
+    dA, dB = mA.flat_params.cpu() - p_init, mB.flat_params.cpu() - p_init
+    assert float(dB.abs().max()) > 0 and float((dA - dB).norm() / dB.norm()) <= 1e-2, float((dA - dB).norm() / dB.norm())
+    for k in ("backbone.0.cbl.1.running_mean", "neck.7.c_out.cbl.1.running_var", "backbone.0.cbl.1.num_batches_tracked"):
+        a, b = mA.state_dict()[k].float().cpu(), mB.state_dict()[k].float().cpu()
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-6), k
