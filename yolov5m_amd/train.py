@@ -9,7 +9,8 @@ both write / read the reference's `{"state_dict", "optimizer"}` checkpoints (uti
 
     python -m yolov5m_amd.train --synthetic 4 --bs 8 --size 320 --epochs 2 [--ultralytics_loss] [--resume --filename model_1]
 runs the same flow on synthetic uint8 batches (no dataset in this repository): what bench.py's step does, through the reference's
-entry points, with checkpoints.
+entry points, with checkpoints. Under `python -m torch.distributed.run --nproc-per-node N -m yolov5m_amd.train ...` it is data parallel
+(one process per GPU, gradients summed over RCCL, rank 0 writes the checkpoints).
 """
 import argparse
 import os
@@ -17,7 +18,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, config
+from . import _lib, config, parallel
 from .loss import YOLO_LOSS
 from .model import YOLOV5m
 from .ultralytics_loss import ComputeLoss
@@ -50,7 +51,21 @@ def train(train_loader, val_loader=None, epochs=1, ultralytics_loss=False, rect=
         model = YOLOV5m(first_out=config.FIRST_OUT, nc=nc, anchors=config.ANCHORS,
                         ch=(config.FIRST_OUT * 4, config.FIRST_OUT * 8, config.FIRST_OUT * 16)).to(config.DEVICE)        # :58-59
     model.compute_dtype = dtype
+    # data parallel (no counterpart in the reference; parallel.py): when the process group is up (parallel.init_from_env under
+    # torch.distributed.run) every rank runs this flow on ITS loader, the gradients are summed over the ranks before the optimizer
+    # (bucketed and overlapped with the backward pass when no accumulation is in the way), rank 0 writes the checkpoints
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if world > 1:
+        if not fused:
+            raise _lib.Y5MError("train: data parallelism goes through the fused step (the gradient exchange is its grad_hook)")
+        grad_hook = grad_hook or parallel.GradAllReduce(world)
     filename, last_epoch = _run_name(resume, filename, checkpoint_root)
+    if world > 1:                                           # (one run name for all ranks: rank 0's)
+        names = [filename]
+        dist.broadcast_object_list(names, src=0)
+        filename = names[0]
     loss_fn = (ComputeLoss(model, save_logs=save_logs, filename=filename, resume=resume) if ultralytics_loss else
                YOLO_LOSS(model, rect_training=rect, save_logs=save_logs, filename=filename, resume=resume))               # :102-106
     if fused:
@@ -63,6 +78,7 @@ def train(train_loader, val_loader=None, epochs=1, ultralytics_loss=False, rect=
         load_model_checkpoint(filename, model, last_epoch, root=checkpoint_root)
         load_optim_checkpoint(filename, optim, last_epoch, root=checkpoint_root)
         starting_epoch = last_epoch + 1
+    parallel.broadcast_parameters(model)                    # (no-op with one rank: every replica starts from rank 0's weights)
     evaluate = YOLO_EVAL(save_logs=save_logs, conf_threshold=config.CONF_THRESHOLD, nms_iou_thresh=config.NMS_IOU_THRESH,
                          map_iou_thresh=config.MAP_IOU_THRESH, device=config.DEVICE, filename=filename, resume=resume)   # :108-111
     losses = []
@@ -75,7 +91,7 @@ def train(train_loader, val_loader=None, epochs=1, ultralytics_loss=False, rect=
         if val_loader is not None:
             evaluate.check_class_accuracy(model, val_loader)                                                              # :127
             evaluate.map_pr_rec(model, val_loader, anchors=model.head.anchors, epoch=epoch)                               # :129
-        if save_model:
+        if save_model and rank == 0:
             save_checkpoint(make_checkpoint(model, optim), folder_path=checkpoint_root, filename=filename, epoch=epoch)   # :136-140
     return model, optim, losses
 
@@ -84,13 +100,13 @@ class SyntheticLoader:
     """n batches of uint8 images + labels in the format the chosen loss's collate function produces (dataset.py:199-209); the same
     batches every epoch (seeded), 8 boxes per image as in BASELINE.json configs[2]"""
 
-    def __init__(self, n, batch, size, ultralytics_loss, boxes_per_image=8):
+    def __init__(self, n, batch, size, ultralytics_loss, boxes_per_image=8, rank=0):
         from .utils.synth import synth_labels
-        g = torch.Generator().manual_seed(0)
+        g = torch.Generator().manual_seed(rank)
         self.batches = []
         for i in range(n):
             img = torch.randint(0, 256, (batch, 3, size, size), generator=g, dtype=torch.uint8)
-            lab = synth_labels(batch, boxes_per_image, seed=f"train/lab{i}")
+            lab = synth_labels(batch, boxes_per_image, seed=f"train/lab{i}/rank{rank}")
             if not ultralytics_loss:
                 t = lab.numpy().astype(np.float64)
                 lab = tuple(t[t[:, 0] == b][:, 1:] for b in range(batch))
@@ -118,11 +134,12 @@ def main(argv=None):
     ap.add_argument("--no-fused", action="store_true", help="torch.optim.Adam + autograd instead of the fused NativeTrainStep")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     a = ap.parse_args(argv)
-    loader = SyntheticLoader(a.synthetic, a.bs, a.size, a.ultralytics_loss)
+    rank, _, world = parallel.init_from_env()               # torch.distributed.run: one process per GPU, RCCL (--bs is per GPU)
+    loader = SyntheticLoader(a.synthetic, a.bs, a.size, a.ultralytics_loss, rank=rank)
     _, _, losses = train(loader, epochs=a.epochs, ultralytics_loss=a.ultralytics_loss, rect=a.rect, filename=a.filename, resume=a.resume,
                          save_model=not a.nosavemodel, save_logs=not a.nosavelogs, fused=not a.no_fused, dtype=a.dtype, nt_max=a.bs * 8)
     for i, l in enumerate(losses):
-        print(f"epoch {i + 1}: training_loss {l:.4f}")
+        print(f"[rank {rank} of {world}] epoch {i + 1}: training_loss {l:.4f}")
 
 
 if __name__ == "__main__":
